@@ -1,0 +1,129 @@
+"""ctypes binding of the C ABI in include/flowmpm.h (flow_amd/lib/libflowmpm.so).
+
+There is no CPU fallback: a missing library raises at import of the binding, and
+a missing GPU makes every computing call fail with FLOWMPM_ERR_HIP.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libflowmpm.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_CAPACITY = 0, 1, 2, 3, 4
+PARTICLE_STRIDE = 28
+KERNEL_CLEAR_GRID, KERNEL_P2G1, KERNEL_P2G2, KERNEL_UPDATE_GRID, KERNEL_G2P = range(5)
+KERNEL_NAMES = ("clearGrid", "p2g1", "p2g2", "updateGrid", "g2p")
+TIMING_REBIN, TIMING_SLOTS = 5, 8
+ALGO_SCATTER, ALGO_TILED = 0, 1
+FIELD_POSITION, FIELD_VELOCITY, FIELD_DENSITY, FIELD_COLOR, FIELD_DIRECTION, FIELD_MASS = range(6)
+FIELD_WIDTH = {FIELD_POSITION: 3, FIELD_VELOCITY: 3, FIELD_DENSITY: 1, FIELD_COLOR: 3,
+               FIELD_DIRECTION: 3, FIELD_MASS: 1}
+PLANE_LOW_HALO, PLANE_LOW_OWNED, PLANE_HIGH_OWNED, PLANE_HIGH_HALO = range(4)
+COMP_MOMENTUM, COMP_MASS, COMP_ALL = 0x7, 0x8, 0xF
+MIGRATE_WORDS = 24
+
+# Every symbol include/flowmpm.h declares.
+EXPORTS = (
+    "flowmpm_version", "flowmpm_device_count", "flowmpm_create", "flowmpm_destroy",
+    "flowmpm_last_error", "flowmpm_upload_particles", "flowmpm_set_num_particles",
+    "flowmpm_get_num_particles", "flowmpm_set_uniforms", "flowmpm_step", "flowmpm_run_kernel",
+    "flowmpm_synchronize", "flowmpm_download_particles", "flowmpm_download_field",
+    "flowmpm_get_local_grid", "flowmpm_download_grid_i32", "flowmpm_download_grid_f32",
+    "flowmpm_set_profiling", "flowmpm_get_timings", "flowmpm_reset_timings", "flowmpm_plane_ptr",
+    "flowmpm_plane_add_i32", "flowmpm_plane_copy_out", "flowmpm_extract_leavers",
+    "flowmpm_insert_arrivals",
+)
+
+
+class Config(ctypes.Structure):
+    _fields_ = [
+        ("grid_x", ctypes.c_int32), ("grid_y", ctypes.c_int32), ("grid_z", ctypes.c_int32),
+        ("slab_x0", ctypes.c_int32), ("slab_nx", ctypes.c_int32),
+        ("device", ctypes.c_int32), ("algorithm", ctypes.c_int32),
+        ("rebin_interval", ctypes.c_int32),
+        ("max_particles", ctypes.c_int64),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
+class Uniforms(ctypes.Structure):
+    _fields_ = [
+        ("dt", ctypes.c_float), ("stiffness", ctypes.c_float), ("rest_density", ctypes.c_float),
+        ("dynamic_viscosity", ctypes.c_float), ("noise", ctypes.c_float), ("time", ctypes.c_float),
+        ("mouse_ray_direction", ctypes.c_float * 3),
+        ("mouse_ray_origin", ctypes.c_float * 3),
+        ("mouse_force", ctypes.c_float * 3),
+        ("cursor_interaction", ctypes.c_uint32),
+        ("hide_percentage", ctypes.c_float),
+        ("grid_mode", ctypes.c_uint32),
+        ("front_gravity_mode", ctypes.c_uint32),
+    ]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [("ms", ctypes.c_double * TIMING_SLOTS), ("launches", ctypes.c_int64 * TIMING_SLOTS)]
+
+
+class FlowMpmError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("flowmpm error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads libflowmpm.so once and declares every prototype.  Raises if the
+    library has not been built (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "flow_amd: %s is missing -- build it with __graft_entry__.build(); "
+            "there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32
+    fp = ctypes.POINTER(ctypes.c_float)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    protos = {
+        "flowmpm_version": ([], ctypes.c_int),
+        "flowmpm_device_count": ([ctypes.POINTER(ctypes.c_int)], ctypes.c_int),
+        "flowmpm_create": ([ctypes.POINTER(Config), ctypes.POINTER(vp)], ctypes.c_int),
+        "flowmpm_destroy": ([vp], ctypes.c_int),
+        "flowmpm_last_error": ([vp], ctypes.c_char_p),
+        "flowmpm_upload_particles": ([vp, fp, ip, i64], ctypes.c_int),
+        "flowmpm_set_num_particles": ([vp, i64], ctypes.c_int),
+        "flowmpm_get_num_particles": ([vp, i64p, i64p], ctypes.c_int),
+        "flowmpm_set_uniforms": ([vp, ctypes.POINTER(Uniforms)], ctypes.c_int),
+        "flowmpm_step": ([vp, i32, ctypes.c_double], ctypes.c_int),
+        "flowmpm_run_kernel": ([vp, i32], ctypes.c_int),
+        "flowmpm_synchronize": ([vp], ctypes.c_int),
+        "flowmpm_download_particles": ([vp, fp, ip, i64, i64p], ctypes.c_int),
+        "flowmpm_download_field": ([vp, i32, fp, i64], ctypes.c_int),
+        "flowmpm_get_local_grid": ([vp, ip, ip], ctypes.c_int),
+        "flowmpm_download_grid_i32": ([vp, ip, i64], ctypes.c_int),
+        "flowmpm_download_grid_f32": ([vp, fp, i64], ctypes.c_int),
+        "flowmpm_set_profiling": ([vp, i32], ctypes.c_int),
+        "flowmpm_get_timings": ([vp, ctypes.POINTER(Timings)], ctypes.c_int),
+        "flowmpm_reset_timings": ([vp], ctypes.c_int),
+        "flowmpm_plane_ptr": ([vp, i32, ctypes.POINTER(vp), i64p], ctypes.c_int),
+        "flowmpm_plane_add_i32": ([vp, i32, vp, u32], ctypes.c_int),
+        "flowmpm_plane_copy_out": ([vp, i32, vp], ctypes.c_int),
+        "flowmpm_extract_leavers": ([vp, ip, i32, vp, i64, i64p], ctypes.c_int),
+        "flowmpm_insert_arrivals": ([vp, vp, i64], ctypes.c_int),
+    }
+    for name, (argtypes, restype) in protos.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = L
+    return L
+
+
+def check(handle, code):
+    if code != OK:
+        msg = load().flowmpm_last_error(handle)
+        raise FlowMpmError(code, msg.decode() if msg else "")

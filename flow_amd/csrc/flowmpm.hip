@@ -1,0 +1,743 @@
+// C ABI of the MI355X MLS-MPM step (declared in include/flowmpm.h).
+//
+// Host side of the library: owns the device buffers of one handle, validates
+// shapes before every launch, and enqueues the kernels of kernels_scatter.h /
+// kernels_tiled.h on the handle's HIP stream.  There is no CPU fallback: every
+// entry point that computes needs a HIP device and fails with FLOWMPM_ERR_HIP
+// otherwise.
+#include "../../include/flowmpm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels_scatter.h"
+#include "kernels_tiled.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct EventPair {
+    hipEvent_t start, stop;
+    int slot;
+};
+
+}  // namespace
+
+struct flowmpm_sim {
+    flowmpm_config cfg{};
+    mpm::Params params{};
+    flowmpm_uniforms uniforms{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool slab = false;
+
+    long long capacity = 0;      // slots in the store
+    long long resident = 0;      // particles on the device
+    long long live = 0;          // simulated particles (== resident except set_num_particles)
+    long long uploaded = 0;      // records given to upload (single GPU)
+    mpm::Store store{};
+    mpm::Store store_alt{};      // tiled: re-binning target
+    int4 *cell = nullptr;
+    float4 *cellf = nullptr;
+    long long local_cells = 0;
+    std::vector<float> shadow;   // host copy of records beyond `live` (single GPU)
+
+    mpm::TiledState tiled{};     // bins, work items (FLOWMPM_ALGO_TILED)
+
+    int *mig_counters = nullptr;   // device scratch for extract_leavers
+    int *mig_lists = nullptr;
+    long long mig_list_cap = 0;
+
+    bool profiling = false;
+    std::vector<EventPair> events;
+    size_t events_used = 0;
+    flowmpm_timings timings{};
+
+    std::string err;
+};
+
+namespace {
+
+int fail(flowmpm_sim *sim, int code, const std::string &msg)
+{
+    if (sim) sim->err = msg;
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(sim, expr)                                                            \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return fail(sim, FLOWMPM_ERR_HIP,                                         \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+#define CHECK_SIM(sim)                                                                \
+    do {                                                                              \
+        if (!(sim)) return fail(nullptr, FLOWMPM_ERR_INVALID, "null handle");         \
+        hipError_t d_ = hipSetDevice((sim)->cfg.device);                              \
+        if (d_ != hipSuccess)                                                         \
+            return fail(sim, FLOWMPM_ERR_HIP,                                         \
+                        std::string("hipSetDevice: ") + hipGetErrorString(d_));       \
+    } while (0)
+
+inline unsigned blocks_for(long long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+void refresh_params(flowmpm_sim *s)
+{
+    mpm::Params &P = s->params;
+    P.gx = s->cfg.grid_x; P.gy = s->cfg.grid_y; P.gz = s->cfg.grid_z;
+    if (s->slab) {
+        P.x_off = s->cfg.slab_x0 - 1;
+        P.local_nx = s->cfg.slab_nx + 2;
+    } else {
+        P.x_off = 0;
+        P.local_nx = s->cfg.grid_x;
+    }
+    const flowmpm_uniforms &u = s->uniforms;
+    P.dt = u.dt; P.stiffness = u.stiffness; P.rest_density = u.rest_density;
+    P.dynamic_viscosity = u.dynamic_viscosity; P.noise = u.noise; P.time = u.time;
+    for (int a = 0; a < 3; a++) {
+        P.ray_dir[a] = u.mouse_ray_direction[a];
+        P.ray_origin[a] = u.mouse_ray_origin[a];
+        P.mouse_force[a] = u.mouse_force[a];
+    }
+    P.cursor_interaction = u.cursor_interaction;
+}
+
+// ---- timing -----------------------------------------------------------------
+
+int timing_begin(flowmpm_sim *s, int slot, size_t *idx)
+{
+    *idx = (size_t)-1;
+    if (!s->profiling) return FLOWMPM_OK;
+    if (s->events_used == s->events.size()) {
+        EventPair p{};
+        HIP_TRY(s, hipEventCreate(&p.start));
+        HIP_TRY(s, hipEventCreate(&p.stop));
+        s->events.push_back(p);
+    }
+    *idx = s->events_used++;
+    s->events[*idx].slot = slot;
+    HIP_TRY(s, hipEventRecord(s->events[*idx].start, s->stream));
+    return FLOWMPM_OK;
+}
+
+int timing_end(flowmpm_sim *s, size_t idx)
+{
+    if (idx == (size_t)-1) return FLOWMPM_OK;
+    HIP_TRY(s, hipEventRecord(s->events[idx].stop, s->stream));
+    return FLOWMPM_OK;
+}
+
+int timing_collect(flowmpm_sim *s)
+{
+    if (s->events_used == 0) return FLOWMPM_OK;
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    for (size_t i = 0; i < s->events_used; i++) {
+        float ms = 0.0f;
+        HIP_TRY(s, hipEventElapsedTime(&ms, s->events[i].start, s->events[i].stop));
+        s->timings.ms[s->events[i].slot] += ms;
+        s->timings.launches[s->events[i].slot] += 1;
+    }
+    s->events_used = 0;
+    return FLOWMPM_OK;
+}
+
+// ---- the five stages ----------------------------------------------------------
+
+int launch_check(flowmpm_sim *s, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(s, FLOWMPM_ERR_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
+    return FLOWMPM_OK;
+}
+
+int stage_clear_grid(flowmpm_sim *s)
+{
+    size_t t;
+    int rc = timing_begin(s, FLOWMPM_KERNEL_CLEAR_GRID, &t);
+    if (rc) return rc;
+    unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
+    hipLaunchKernelGGL(mpm::clear_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, s->cell,
+                       s->cellf, s->local_cells);
+    if ((rc = launch_check(s, "clear_grid"))) return rc;
+    return timing_end(s, t);
+}
+
+int stage_rebin_if_needed(flowmpm_sim *s);
+
+int stage_p2g1(flowmpm_sim *s)
+{
+    int rc;
+    if (s->cfg.algorithm == FLOWMPM_ALGO_TILED && (rc = stage_rebin_if_needed(s))) return rc;
+    size_t t;
+    if ((rc = timing_begin(s, FLOWMPM_KERNEL_P2G1, &t))) return rc;
+    if (s->live > 0) {
+        if (s->cfg.algorithm == FLOWMPM_ALGO_TILED) {
+            if ((rc = mpm::launch_p2g1_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream)))
+                return fail(s, FLOWMPM_ERR_HIP, "p2g1_tiled launch failed");
+        } else {
+            hipLaunchKernelGGL(mpm::p2g1_scatter_kernel, dim3(blocks_for(s->live, 256)), dim3(256), 0,
+                               s->stream, s->store, s->live, reinterpret_cast<int *>(s->cell), s->params);
+        }
+        if ((rc = launch_check(s, "p2g1"))) return rc;
+    }
+    return timing_end(s, t);
+}
+
+int stage_p2g2(flowmpm_sim *s)
+{
+    int rc;
+    if (s->cfg.algorithm == FLOWMPM_ALGO_TILED && (rc = stage_rebin_if_needed(s))) return rc;
+    size_t t;
+    if ((rc = timing_begin(s, FLOWMPM_KERNEL_P2G2, &t))) return rc;
+    if (s->live > 0) {
+        if (s->cfg.algorithm == FLOWMPM_ALGO_TILED) {
+            if ((rc = mpm::launch_p2g2_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream)))
+                return fail(s, FLOWMPM_ERR_HIP, "p2g2_tiled launch failed");
+        } else {
+            hipLaunchKernelGGL(mpm::p2g2_scatter_kernel, dim3(blocks_for(s->live, 256)), dim3(256), 0,
+                               s->stream, s->store, s->live, reinterpret_cast<int *>(s->cell), s->params);
+        }
+        if ((rc = launch_check(s, "p2g2"))) return rc;
+    }
+    return timing_end(s, t);
+}
+
+int stage_update_grid(flowmpm_sim *s)
+{
+    size_t t;
+    int rc = timing_begin(s, FLOWMPM_KERNEL_UPDATE_GRID, &t);
+    if (rc) return rc;
+    unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
+    hipLaunchKernelGGL(mpm::update_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, s->cell,
+                       s->cellf, s->local_cells, s->params);
+    if ((rc = launch_check(s, "update_grid"))) return rc;
+    return timing_end(s, t);
+}
+
+int stage_g2p(flowmpm_sim *s)
+{
+    int rc;
+    if (s->cfg.algorithm == FLOWMPM_ALGO_TILED && (rc = stage_rebin_if_needed(s))) return rc;
+    size_t t;
+    if ((rc = timing_begin(s, FLOWMPM_KERNEL_G2P, &t))) return rc;
+    if (s->live > 0) {
+        if (s->cfg.algorithm == FLOWMPM_ALGO_TILED) {
+            if ((rc = mpm::launch_g2p_tiled(s->tiled, s->store, s->live, s->cellf, s->params, s->stream)))
+                return fail(s, FLOWMPM_ERR_HIP, "g2p_tiled launch failed");
+            s->tiled.steps_since_rebin += 1;
+        } else {
+            hipLaunchKernelGGL(mpm::g2p_gather_kernel, dim3(blocks_for(s->live, 256)), dim3(256), 0,
+                               s->stream, s->store, s->live, s->cellf, s->params);
+        }
+        if ((rc = launch_check(s, "g2p"))) return rc;
+    }
+    return timing_end(s, t);
+}
+
+// Tiled algorithm: particles must be grouped by grid tile before the first
+// particle kernel of a step; regroup when the grouping is missing or stale.
+int stage_rebin_if_needed(flowmpm_sim *s)
+{
+    mpm::TiledState &T = s->tiled;
+    if (T.valid && T.steps_since_rebin < s->cfg.rebin_interval) return FLOWMPM_OK;
+    if (s->live == 0) { T.valid = true; T.steps_since_rebin = 0; return FLOWMPM_OK; }
+    size_t t;
+    int rc = timing_begin(s, FLOWMPM_TIMING_REBIN, &t);
+    if (rc) return rc;
+    std::string msg;
+    if (mpm::rebin(T, s->store, s->store_alt, s->live, s->params, s->stream, &msg))
+        return fail(s, FLOWMPM_ERR_HIP, "rebin: " + msg);
+    std::swap(s->store, s->store_alt);
+    return timing_end(s, t);
+}
+
+int validate_uniforms(flowmpm_sim *s, const flowmpm_uniforms *u)
+{
+    if (u->grid_mode != 0)
+        return fail(s, FLOWMPM_ERR_UNSUPPORTED, "gridMode != 0 (image modes) is not implemented");
+    if (u->front_gravity_mode != 0)
+        return fail(s, FLOWMPM_ERR_UNSUPPORTED, "frontGravityMode != 0 is not implemented");
+    if (u->hide_percentage != 0.0f)
+        return fail(s, FLOWMPM_ERR_UNSUPPORTED, "hidePercentage != 0 is not implemented");
+    if (u->cursor_interaction > 1u)
+        return fail(s, FLOWMPM_ERR_INVALID, "cursorInteraction must be 0 or 1");
+    return FLOWMPM_OK;
+}
+
+int alloc_store(flowmpm_sim *s, mpm::Store *st)
+{
+    st->capacity = s->capacity;
+    size_t bytes = (size_t)mpm::kNumSlots * (size_t)s->capacity * sizeof(float);
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&st->base), bytes));
+    HIP_TRY(s, hipMemsetAsync(st->base, 0, bytes, s->stream));
+    return FLOWMPM_OK;
+}
+
+// Uploads `count` host records into slots [first_slot, first_slot + count).
+int upload_records(flowmpm_sim *s, const float *aos, const int32_t *ids, long long first_slot,
+                   long long count)
+{
+    if (count == 0) return FLOWMPM_OK;
+    float *d_aos = nullptr;
+    int *d_ids = nullptr;
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&d_aos), (size_t)count * 28 * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d_aos, aos, (size_t)count * 28 * sizeof(float),
+                                  hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess && ids) {
+        e = hipMalloc(reinterpret_cast<void **>(&d_ids), (size_t)count * sizeof(int));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(d_ids, ids, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s->stream);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mpm::aos_to_soa_kernel, dim3(blocks_for(count, 256)), dim3(256), 0, s->stream,
+                           d_aos, d_ids, s->store, first_slot, count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_aos);
+    if (d_ids) (void)hipFree(d_ids);
+    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
+    return FLOWMPM_OK;
+}
+
+// Positions must keep the 3x3x3 stencil inside the planes this handle holds.
+int validate_positions(flowmpm_sim *s, const float *aos, long long count)
+{
+    const float lo_x = s->slab ? (float)s->cfg.slab_x0 : 1.0f;
+    const float hi_x = s->slab ? (float)(s->cfg.slab_x0 + s->cfg.slab_nx) : (float)(s->cfg.grid_x - 1);
+    const float hi_y = (float)(s->cfg.grid_y - 1), hi_z = (float)(s->cfg.grid_z - 1);
+    for (long long i = 0; i < count; i++) {
+        const float *p = aos + i * 28;
+        bool ok = p[0] >= lo_x && p[0] < hi_x && p[1] >= 1.0f && p[1] < hi_y && p[2] >= 1.0f && p[2] < hi_z;
+        if (!ok || !(p[0] >= 1.0f && p[0] < (float)(s->cfg.grid_x - 1))) {
+            char buf[200];
+            snprintf(buf, sizeof buf,
+                     "particle %lld position (%g, %g, %g) puts its stencil outside the grid planes of this handle",
+                     i, p[0], p[1], p[2]);
+            return fail(s, FLOWMPM_ERR_INVALID, buf);
+        }
+    }
+    return FLOWMPM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int flowmpm_version(void) { return 100; }
+
+int flowmpm_device_count(int *count)
+{
+    if (!count) return fail(nullptr, FLOWMPM_ERR_INVALID, "null count");
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, FLOWMPM_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    return FLOWMPM_OK;
+}
+
+const char *flowmpm_last_error(const flowmpm_sim *sim)
+{
+    return sim ? sim->err.c_str() : g_last_error.c_str();
+}
+
+int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
+{
+    if (!config || !out) return fail(nullptr, FLOWMPM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const flowmpm_config &c = *config;
+    if (c.grid_x < 6 || c.grid_y < 6 || c.grid_z < 6)
+        return fail(nullptr, FLOWMPM_ERR_INVALID, "grid must be at least 6 cells on every axis");
+    if ((long long)c.grid_x * c.grid_y * c.grid_z > 2147483647LL / 4)
+        return fail(nullptr, FLOWMPM_ERR_INVALID, "grid too large for 32-bit cell indexing");
+    if (c.max_particles < 0 || c.max_particles > 2147483647LL)
+        return fail(nullptr, FLOWMPM_ERR_INVALID, "max_particles out of range");
+    if (c.algorithm != FLOWMPM_ALGO_SCATTER && c.algorithm != FLOWMPM_ALGO_TILED)
+        return fail(nullptr, FLOWMPM_ERR_INVALID, "unknown algorithm");
+    if (c.slab_nx < 0 || c.slab_x0 < 0 || c.slab_x0 + c.slab_nx > c.grid_x)
+        return fail(nullptr, FLOWMPM_ERR_INVALID, "slab outside the grid");
+    if (c.slab_nx > 0 && c.slab_nx < 2)
+        return fail(nullptr, FLOWMPM_ERR_INVALID, "a slab needs at least 2 planes");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, FLOWMPM_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (c.device < 0 || c.device >= ndev) return fail(nullptr, FLOWMPM_ERR_INVALID, "bad device ordinal");
+
+    flowmpm_sim *s = new flowmpm_sim();
+    s->cfg = c;
+    if (s->cfg.rebin_interval < 1) s->cfg.rebin_interval = 1;
+    s->slab = c.slab_nx > 0;
+    s->capacity = std::max<long long>(c.max_particles, 1);
+    // keep every slot array 256-byte aligned
+    s->capacity = (s->capacity + 63) / 64 * 64;
+
+    int rc = FLOWMPM_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(s, hipSetDevice(c.device));
+        if (c.stream) {
+            s->stream = reinterpret_cast<hipStream_t>(c.stream);
+        } else {
+            HIP_TRY(s, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+            s->own_stream = true;
+        }
+        refresh_params(s);
+        s->local_cells = (long long)s->params.local_nx * c.grid_y * c.grid_z;
+        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->cell), (size_t)s->local_cells * sizeof(int4)));
+        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->cellf), (size_t)s->local_cells * sizeof(float4)));
+        HIP_TRY(s, hipMemsetAsync(s->cell, 0, (size_t)s->local_cells * sizeof(int4), s->stream));
+        HIP_TRY(s, hipMemsetAsync(s->cellf, 0, (size_t)s->local_cells * sizeof(float4), s->stream));
+        int r = alloc_store(s, &s->store);
+        if (r) return r;
+        if (c.algorithm == FLOWMPM_ALGO_TILED) {
+            if ((r = alloc_store(s, &s->store_alt))) return r;
+            std::string msg;
+            if (mpm::tiled_init(s->tiled, s->params, s->capacity, s->stream, &msg))
+                return fail(s, FLOWMPM_ERR_HIP, "tiled_init: " + msg);
+        }
+        HIP_TRY(s, hipStreamSynchronize(s->stream));
+        return FLOWMPM_OK;
+    };
+    rc = body();
+    if (rc != FLOWMPM_OK) {
+        g_last_error = s->err;
+        flowmpm_destroy(s);
+        return rc;
+    }
+    // reference defaults of the uniforms that have one (SIM:150)
+    s->uniforms.dt = 0.1f;
+    refresh_params(s);
+    *out = s;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_destroy(flowmpm_sim *s)
+{
+    if (!s) return FLOWMPM_OK;
+    (void)hipSetDevice(s->cfg.device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto &p : s->events) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+    mpm::tiled_free(s->tiled);
+    if (s->store.base) (void)hipFree(s->store.base);
+    if (s->store_alt.base) (void)hipFree(s->store_alt.base);
+    if (s->cell) (void)hipFree(s->cell);
+    if (s->cellf) (void)hipFree(s->cellf);
+    if (s->mig_counters) (void)hipFree(s->mig_counters);
+    if (s->mig_lists) (void)hipFree(s->mig_lists);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_upload_particles(flowmpm_sim *s, const float *aos, const int32_t *ids, int64_t count)
+{
+    CHECK_SIM(s);
+    if (count < 0 || (count > 0 && !aos)) return fail(s, FLOWMPM_ERR_INVALID, "bad particle array");
+    if (count > s->cfg.max_particles)
+        return fail(s, FLOWMPM_ERR_CAPACITY, "more particles than max_particles");
+    if (!s->slab && ids) return fail(s, FLOWMPM_ERR_INVALID, "explicit ids are for slab handles only");
+    int rc = validate_positions(s, aos, count);
+    if (rc) return rc;
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    if ((rc = upload_records(s, aos, ids, 0, count))) return rc;
+    s->resident = s->live = s->uploaded = count;
+    s->shadow.clear();
+    s->tiled.valid = false;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_get_num_particles(flowmpm_sim *s, int64_t *live, int64_t *resident)
+{
+    if (!s) return fail(nullptr, FLOWMPM_ERR_INVALID, "null handle");
+    if (live) *live = s->live;
+    if (resident) *resident = s->slab ? s->resident : s->uploaded;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_set_uniforms(flowmpm_sim *s, const flowmpm_uniforms *u)
+{
+    if (!s || !u) return fail(s, FLOWMPM_ERR_INVALID, "null argument");
+    int rc = validate_uniforms(s, u);
+    if (rc) return rc;
+    s->uniforms = *u;
+    refresh_params(s);
+    return FLOWMPM_OK;
+}
+
+int flowmpm_run_kernel(flowmpm_sim *s, int32_t kernel_id)
+{
+    CHECK_SIM(s);
+    switch (kernel_id) {
+    case FLOWMPM_KERNEL_CLEAR_GRID: return stage_clear_grid(s);
+    case FLOWMPM_KERNEL_P2G1: return stage_p2g1(s);
+    case FLOWMPM_KERNEL_P2G2: return stage_p2g2(s);
+    case FLOWMPM_KERNEL_UPDATE_GRID: return stage_update_grid(s);
+    case FLOWMPM_KERNEL_G2P: return stage_g2p(s);
+    default: return fail(s, FLOWMPM_ERR_INVALID, "unknown kernel id");
+    }
+}
+
+int flowmpm_step(flowmpm_sim *s, int32_t n_steps, double dtime)
+{
+    CHECK_SIM(s);
+    if (n_steps < 0) return fail(s, FLOWMPM_ERR_INVALID, "negative step count");
+    const float time0 = s->uniforms.time;
+    int rc = FLOWMPM_OK;
+    for (int k = 0; k < n_steps && rc == FLOWMPM_OK; k++) {
+        s->params.time = (float)((double)time0 + (double)k * dtime);
+        if ((rc = stage_clear_grid(s))) break;
+        if ((rc = stage_p2g1(s))) break;
+        if ((rc = stage_p2g2(s))) break;
+        if ((rc = stage_update_grid(s))) break;
+        if ((rc = stage_g2p(s))) break;
+        // bound the number of live event pairs
+        if (s->profiling && s->events_used > 4096 && (rc = timing_collect(s))) break;
+    }
+    s->params.time = time0;
+    return rc;
+}
+
+int flowmpm_synchronize(flowmpm_sim *s)
+{
+    CHECK_SIM(s);
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    return FLOWMPM_OK;
+}
+
+int flowmpm_download_particles(flowmpm_sim *s, float *aos, int32_t *ids, int64_t capacity, int64_t *count)
+{
+    CHECK_SIM(s);
+    const long long total = s->slab ? s->resident : s->uploaded;
+    if (count) *count = total;
+    if (!aos || capacity < total) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
+    if (total == 0) return FLOWMPM_OK;
+    float *d_aos = nullptr;
+    int *d_ids = nullptr;
+    const long long n = s->resident;
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&d_aos), (size_t)std::max<long long>(n, 1) * 28 * sizeof(float)));
+    hipError_t e = hipSuccess;
+    if (s->slab) e = hipMalloc(reinterpret_cast<void **>(&d_ids), (size_t)std::max<long long>(n, 1) * sizeof(int));
+    if (e == hipSuccess && n > 0) {
+        hipLaunchKernelGGL(mpm::soa_to_aos_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->store,
+                           n, d_aos, d_ids, s->slab ? 0 : 1);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(aos, d_aos, (size_t)n * 28 * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && s->slab && ids)
+        e = hipMemcpyAsync(ids, d_ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_aos);
+    if (d_ids) (void)hipFree(d_ids);
+    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("download: ") + hipGetErrorString(e));
+    if (!s->slab && s->uploaded > s->resident)   // records beyond the live count are host-held
+        memcpy(aos + s->resident * 28, s->shadow.data(), (size_t)(s->uploaded - s->resident) * 28 * sizeof(float));
+    return FLOWMPM_OK;
+}
+
+int flowmpm_set_num_particles(flowmpm_sim *s, int64_t count)
+{
+    CHECK_SIM(s);
+    if (s->slab) return fail(s, FLOWMPM_ERR_INVALID, "set_num_particles is for single-GPU handles");
+    if (count < 0 || count > s->uploaded) return fail(s, FLOWMPM_ERR_INVALID, "count exceeds uploaded particles");
+    if (count == s->live) return FLOWMPM_OK;
+    // Bring every record back in id order, then re-upload the first `count`.
+    std::vector<float> all((size_t)s->uploaded * 28);
+    int64_t got = 0;
+    int rc = flowmpm_download_particles(s, all.data(), nullptr, s->uploaded, &got);
+    if (rc) return rc;
+    if ((rc = upload_records(s, all.data(), nullptr, 0, count))) return rc;
+    s->resident = s->live = count;
+    s->shadow.assign(all.begin() + (size_t)count * 28, all.end());
+    s->tiled.valid = false;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_download_field(flowmpm_sim *s, int32_t field, float *out, int64_t capacity)
+{
+    CHECK_SIM(s);
+    if (s->slab) return fail(s, FLOWMPM_ERR_INVALID, "download_field is for single-GPU handles");
+    int slot, width;
+    switch (field) {
+    case FLOWMPM_FIELD_POSITION: slot = mpm::kPosX; width = 3; break;
+    case FLOWMPM_FIELD_VELOCITY: slot = mpm::kVelX; width = 3; break;
+    case FLOWMPM_FIELD_DENSITY: slot = mpm::kDensity; width = 1; break;
+    case FLOWMPM_FIELD_COLOR: slot = mpm::kColR; width = 3; break;
+    case FLOWMPM_FIELD_DIRECTION: slot = mpm::kDirX; width = 3; break;
+    case FLOWMPM_FIELD_MASS: slot = mpm::kMass; width = 1; break;
+    default: return fail(s, FLOWMPM_ERR_INVALID, "unknown field");
+    }
+    const long long n = s->resident;
+    if (!out || capacity < n) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
+    if (n == 0) return FLOWMPM_OK;
+    float *d = nullptr;
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&d), (size_t)n * width * sizeof(float)));
+    hipLaunchKernelGGL(mpm::gather_field_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->store, n,
+                       slot, width, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, d, (size_t)n * width * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("download_field: ") + hipGetErrorString(e));
+    return FLOWMPM_OK;
+}
+
+int flowmpm_get_local_grid(flowmpm_sim *s, int32_t *x_first, int32_t *x_planes)
+{
+    if (!s) return fail(nullptr, FLOWMPM_ERR_INVALID, "null handle");
+    if (x_first) *x_first = s->params.x_off;
+    if (x_planes) *x_planes = s->params.local_nx;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_download_grid_i32(flowmpm_sim *s, int32_t *out, int64_t capacity_cells)
+{
+    CHECK_SIM(s);
+    if (!out || capacity_cells < s->local_cells) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
+    HIP_TRY(s, hipMemcpyAsync(out, s->cell, (size_t)s->local_cells * sizeof(int4), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    return FLOWMPM_OK;
+}
+
+int flowmpm_download_grid_f32(flowmpm_sim *s, float *out, int64_t capacity_cells)
+{
+    CHECK_SIM(s);
+    if (!out || capacity_cells < s->local_cells) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
+    HIP_TRY(s, hipMemcpyAsync(out, s->cellf, (size_t)s->local_cells * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    return FLOWMPM_OK;
+}
+
+int flowmpm_set_profiling(flowmpm_sim *s, int32_t enabled)
+{
+    CHECK_SIM(s);
+    int rc = timing_collect(s);
+    if (rc) return rc;
+    s->profiling = enabled != 0;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_get_timings(flowmpm_sim *s, flowmpm_timings *out)
+{
+    CHECK_SIM(s);
+    if (!out) return fail(s, FLOWMPM_ERR_INVALID, "null output");
+    int rc = timing_collect(s);
+    if (rc) return rc;
+    *out = s->timings;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_reset_timings(flowmpm_sim *s)
+{
+    CHECK_SIM(s);
+    int rc = timing_collect(s);
+    if (rc) return rc;
+    s->timings = flowmpm_timings{};
+    return FLOWMPM_OK;
+}
+
+// ---- slab decomposition --------------------------------------------------------
+
+static int plane_index(flowmpm_sim *s, int32_t plane, long long *first_cell)
+{
+    if (!s->slab) return fail(s, FLOWMPM_ERR_INVALID, "not a slab handle");
+    int lx;
+    switch (plane) {
+    case FLOWMPM_PLANE_LOW_HALO: lx = 0; break;
+    case FLOWMPM_PLANE_LOW_OWNED: lx = 1; break;
+    case FLOWMPM_PLANE_HIGH_OWNED: lx = s->cfg.slab_nx; break;
+    case FLOWMPM_PLANE_HIGH_HALO: lx = s->cfg.slab_nx + 1; break;
+    default: return fail(s, FLOWMPM_ERR_INVALID, "unknown plane");
+    }
+    *first_cell = (long long)lx * s->cfg.grid_y * s->cfg.grid_z;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_plane_ptr(flowmpm_sim *s, int32_t plane, void **dev_ptr, int64_t *bytes)
+{
+    if (!s) return fail(nullptr, FLOWMPM_ERR_INVALID, "null handle");
+    long long first;
+    int rc = plane_index(s, plane, &first);
+    if (rc) return rc;
+    if (dev_ptr) *dev_ptr = s->cell + first;
+    if (bytes) *bytes = (int64_t)s->cfg.grid_y * s->cfg.grid_z * (int64_t)sizeof(int4);
+    return FLOWMPM_OK;
+}
+
+int flowmpm_plane_add_i32(flowmpm_sim *s, int32_t plane, const void *dev_src, uint32_t comp_mask)
+{
+    CHECK_SIM(s);
+    long long first;
+    int rc = plane_index(s, plane, &first);
+    if (rc) return rc;
+    if (!dev_src) return fail(s, FLOWMPM_ERR_INVALID, "null source");
+    long long cells = (long long)s->cfg.grid_y * s->cfg.grid_z;
+    hipLaunchKernelGGL(mpm::plane_add_kernel, dim3(blocks_for(cells, 256)), dim3(256), 0, s->stream,
+                       s->cell + first, reinterpret_cast<const int4 *>(dev_src), cells, comp_mask & 0xFu);
+    return launch_check(s, "plane_add");
+}
+
+int flowmpm_plane_copy_out(flowmpm_sim *s, int32_t plane, void *dev_dst)
+{
+    CHECK_SIM(s);
+    long long first;
+    int rc = plane_index(s, plane, &first);
+    if (rc) return rc;
+    if (!dev_dst) return fail(s, FLOWMPM_ERR_INVALID, "null destination");
+    size_t bytes = (size_t)s->cfg.grid_y * s->cfg.grid_z * sizeof(int4);
+    HIP_TRY(s, hipMemcpyAsync(dev_dst, s->cell + first, bytes, hipMemcpyDeviceToDevice, s->stream));
+    return FLOWMPM_OK;
+}
+
+int flowmpm_extract_leavers(flowmpm_sim *s, const int32_t *plane_starts, int32_t n_ranks, void *dev_out,
+                            int64_t capacity_records, int64_t *counts)
+{
+    CHECK_SIM(s);
+    if (!s->slab) return fail(s, FLOWMPM_ERR_INVALID, "not a slab handle");
+    if (!plane_starts || n_ranks < 1 || n_ranks > mpm::kMaxRanks || !counts)
+        return fail(s, FLOWMPM_ERR_INVALID, "bad rank table");
+    std::string msg;
+    long long new_resident = s->resident;
+    int rc = mpm::extract_leavers(s->store, s->resident, s->params, s->cfg.slab_x0, s->cfg.slab_nx, plane_starts,
+                                  n_ranks, reinterpret_cast<float *>(dev_out), capacity_records, counts,
+                                  &s->mig_counters, &s->mig_lists, &s->mig_list_cap, s->stream, &new_resident, &msg);
+    if (rc == 1) return fail(s, FLOWMPM_ERR_HIP, "extract_leavers: " + msg);
+    if (rc == 2) return fail(s, FLOWMPM_ERR_CAPACITY, "extract_leavers: " + msg);
+    if (new_resident != s->resident) s->tiled.valid = false;
+    s->resident = s->live = new_resident;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_insert_arrivals(flowmpm_sim *s, const void *dev_in, int64_t count)
+{
+    CHECK_SIM(s);
+    if (!s->slab) return fail(s, FLOWMPM_ERR_INVALID, "not a slab handle");
+    if (count < 0 || (count > 0 && !dev_in)) return fail(s, FLOWMPM_ERR_INVALID, "bad arrival buffer");
+    if (count == 0) return FLOWMPM_OK;
+    if (s->resident + count > s->cfg.max_particles)
+        return fail(s, FLOWMPM_ERR_CAPACITY, "arrivals exceed max_particles of this slab");
+    hipLaunchKernelGGL(mpm::unpack_records_kernel, dim3(blocks_for(count, 256)), dim3(256), 0, s->stream,
+                       reinterpret_cast<const float *>(dev_in), s->store, (long long)s->resident, (long long)count);
+    int rc = launch_check(s, "insert_arrivals");
+    if (rc) return rc;
+    s->resident += count;
+    s->live = s->resident;
+    s->tiled.valid = false;
+    return FLOWMPM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+// The reference's own algorithm on CDNA4: one thread per particle, every stencil
+// contribution added to the global fixed-point grid with an i32 atomic
+// (SIM:315-331, 377-391), and one thread per cell for the two grid sweeps.
+// This is the baseline path (FLOWMPM_ALGO_SCATTER); the tiled path shares the
+// grid sweeps and the arithmetic in mpm_device.h.
+#pragma once
+
+#include "mpm_device.h"
+
+namespace mpm {
+
+struct Store {
+    float *base;        // kNumSlots arrays of `capacity` elements, slot-major
+    long long capacity;
+    __device__ __host__ __forceinline__ float *slot(int k) const { return base + (long long)k * capacity; }
+    __device__ __host__ __forceinline__ int *ids() const { return reinterpret_cast<int *>(slot(kId)); }
+};
+
+// Local linear cell index (SIM:286-290) or -1 when the cell is outside the planes
+// this handle holds (only reachable from positions the host refused to upload).
+__device__ __forceinline__ long long local_cell(int cx, int cy, int cz, const Params &P)
+{
+    int lx = cx - P.x_off;
+    if ((unsigned)lx >= (unsigned)P.local_nx || (unsigned)cy >= (unsigned)P.gy ||
+        (unsigned)cz >= (unsigned)P.gz)
+        return -1;
+    return ((long long)lx * P.gy + cy) * P.gz + cz;
+}
+
+// SIM:262-277.  One thread clears one cell of both grids with two 16-byte stores.
+__global__ void __launch_bounds__(256)
+clear_grid_kernel(int4 *__restrict__ cell, float4 *__restrict__ cellf, long long cells)
+{
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
+        cell[i] = make_int4(0, 0, 0, 0);
+        cellf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+// SIM:295-333.
+__global__ void __launch_bounds__(256)
+p2g1_scatter_kernel(Store st, long long n, int *__restrict__ cell, Params P)
+{
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
+    float vx = st.slot(kVelX)[j], vy = st.slot(kVelY)[j], vz = st.slot(kVelZ)[j];
+    float C[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) C[k] = st.slot(kC00 + k)[j];
+    Stencil s = make_stencil(px, py, pz);
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++) {
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                float dx = s.dx[gx], dy = s.dy[gy], dz = s.dz[gz];
+                float qx = (C[0] * dx + C[3] * dy) + C[6] * dz;
+                float qy = (C[1] * dx + C[4] * dy) + C[7] * dz;
+                float qz = (C[2] * dx + C[5] * dy) + C[8] * dz;
+                long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                if (c < 0) continue;
+                int *p = cell + 4 * c;
+                atomicAdd(p + 0, encode_fixed(weight * (vx + qx)));
+                atomicAdd(p + 1, encode_fixed(weight * (vy + qy)));
+                atomicAdd(p + 2, encode_fixed(weight * (vz + qz)));
+                atomicAdd(p + 3, encode_fixed(weight));
+            }
+        }
+    }
+}
+
+// SIM:336-392.
+__global__ void __launch_bounds__(256)
+p2g2_scatter_kernel(Store st, long long n, int *__restrict__ cell, Params P)
+{
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
+    float C[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) C[k] = st.slot(kC00 + k)[j];
+    Stencil s = make_stencil(px, py, pz);
+
+    float density = 0.0f;
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                int m = (c >= 0) ? cell[4 * c + 3] : 0;
+                density = density + decode_fixed(m) * weight;
+            }
+        }
+    float *dens = st.slot(kDensity);
+    dens[j] = dens[j] * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
+
+    Eq16 e = p2g2_stress(density, C, P);
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                float dx = s.dx[gx], dy = s.dy[gy], dz = s.dz[gz];
+                float a00 = e.m00 * weight, a11 = e.m11 * weight, a22 = e.m22 * weight;
+                float a01 = e.m01 * weight, a02 = e.m02 * weight, a12 = e.m12 * weight;
+                float mx = (a00 * dx + a01 * dy) + a02 * dz;
+                float my = (a01 * dx + a11 * dy) + a12 * dz;
+                float mz = (a02 * dx + a12 * dy) + a22 * dz;
+                long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                if (c < 0) continue;
+                int *p = cell + 4 * c;
+                atomicAdd(p + 0, encode_fixed(mx));
+                atomicAdd(p + 1, encode_fixed(my));
+                atomicAdd(p + 2, encode_fixed(mz));
+            }
+        }
+}
+
+// SIM:395-429.  Cells with mass <= 0 keep what clearGrid wrote (zeros).
+__global__ void __launch_bounds__(256)
+update_grid_kernel(const int4 *__restrict__ cell, float4 *__restrict__ cellf, long long cells,
+                   Params P)
+{
+    long long stride = (long long)gridDim.x * blockDim.x;
+    const int plane = P.gy * P.gz;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
+        int4 c = cell[i];
+        float mass = decode_fixed(c.w);
+        if (!(mass > 0.0f)) continue;
+        float vx = decode_fixed(c.x) / mass;
+        float vy = decode_fixed(c.y) / mass;
+        float vz = decode_fixed(c.z) / mass;
+        int lx = (int)(i / plane);
+        int rem = (int)(i - (long long)lx * plane);
+        int x = lx + P.x_off, y = rem / P.gz, z = rem - y * P.gz;
+        if (x < 2 || x > P.gx - 2) vx = 0.0f;
+        if (y < 2 || y > P.gy - 2) vy = 0.0f;
+        if (z < 2 || z > P.gz - 2) vz = 0.0f;
+        cellf[i] = make_float4(vx, vy, vz, mass);
+    }
+}
+
+// SIM:431-1536, chaos path, gathering straight from the global float grid.
+__global__ void __launch_bounds__(256)
+g2p_gather_kernel(Store st, long long n, const float4 *__restrict__ cellf, Params P)
+{
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    G2PIn in;
+    in.px = st.slot(kPosX)[j]; in.py = st.slot(kPosY)[j]; in.pz = st.slot(kPosZ)[j];
+    in.mass = st.slot(kMass)[j];
+    in.dirx = st.slot(kDirX)[j]; in.diry = st.slot(kDirY)[j]; in.dirz = st.slot(kDirZ)[j];
+
+    Vec3 v = g2p_pre_forces(in.px, in.py, in.pz, P);
+    Stencil s = make_stencil(in.px, in.py, in.pz);
+    float B[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) B[k] = 0.0f;
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                float4 f = (c >= 0) ? cellf[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                float wvx = f.x * weight, wvy = f.y * weight, wvz = f.z * weight;
+                float dx = s.dx[gx], dy = s.dy[gy], dz = s.dz[gz];
+                B[0] = B[0] + wvx * dx; B[1] = B[1] + wvy * dx; B[2] = B[2] + wvz * dx;
+                B[3] = B[3] + wvx * dy; B[4] = B[4] + wvy * dy; B[5] = B[5] + wvz * dy;
+                B[6] = B[6] + wvx * dz; B[7] = B[7] + wvy * dz; B[8] = B[8] + wvz * dz;
+                v.x = v.x + wvx; v.y = v.y + wvy; v.z = v.z + wvz;
+            }
+        }
+    G2POut o = g2p_finish(in, v, B, P);
+#pragma unroll
+    for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
+    st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;
+    st.slot(kVelX)[j] = o.vx; st.slot(kVelY)[j] = o.vy; st.slot(kVelZ)[j] = o.vz;
+    st.slot(kDirX)[j] = o.dirx; st.slot(kDirY)[j] = o.diry; st.slot(kDirZ)[j] = o.dirz;
+}
+
+// Host AoS record (28 floats, the reference's layout) <-> SoA store.
+__global__ void __launch_bounds__(256)
+aos_to_soa_kernel(const float *__restrict__ aos, const int *__restrict__ ids, Store st,
+                  long long first_slot, long long count)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float *r = aos + i * 28;
+    long long j = first_slot + i;
+    st.slot(kPosX)[j] = r[0]; st.slot(kPosY)[j] = r[1]; st.slot(kPosZ)[j] = r[2];
+    st.slot(kDensity)[j] = r[3];
+    st.slot(kVelX)[j] = r[4]; st.slot(kVelY)[j] = r[5]; st.slot(kVelZ)[j] = r[6];
+    st.slot(kMass)[j] = r[7];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int row = 0; row < 3; row++) st.slot(kC00 + 3 * c + row)[j] = r[8 + 4 * c + row];
+    st.slot(kDirX)[j] = r[20]; st.slot(kDirY)[j] = r[21]; st.slot(kDirZ)[j] = r[22];
+    st.slot(kColR)[j] = r[24]; st.slot(kColG)[j] = r[25]; st.slot(kColB)[j] = r[26];
+    st.ids()[j] = ids ? ids[i] : (int)i;
+}
+
+// dst_by_id != 0: record of the particle in slot j goes to row ids[j] (id order);
+// otherwise to row j, and ids_out[j] receives its id.
+__global__ void __launch_bounds__(256)
+soa_to_aos_kernel(Store st, long long count, float *__restrict__ aos, int *__restrict__ ids_out,
+                  int dst_by_id)
+{
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    int id = st.ids()[j];
+    float *r = aos + (dst_by_id ? (long long)id : j) * 28;
+    r[0] = st.slot(kPosX)[j]; r[1] = st.slot(kPosY)[j]; r[2] = st.slot(kPosZ)[j];
+    r[3] = st.slot(kDensity)[j];
+    r[4] = st.slot(kVelX)[j]; r[5] = st.slot(kVelY)[j]; r[6] = st.slot(kVelZ)[j];
+    r[7] = st.slot(kMass)[j];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int row = 0; row < 3; row++) r[8 + 4 * c + row] = st.slot(kC00 + 3 * c + row)[j];
+        r[8 + 4 * c + 3] = 0.0f;
+    }
+    r[20] = st.slot(kDirX)[j]; r[21] = st.slot(kDirY)[j]; r[22] = st.slot(kDirZ)[j];
+    r[23] = 0.0f;
+    r[24] = st.slot(kColR)[j]; r[25] = st.slot(kColG)[j]; r[26] = st.slot(kColB)[j];
+    r[27] = 0.0f;
+    if (ids_out) ids_out[j] = id;
+}
+
+// One per-particle field in id order (what a renderer binds).
+__global__ void __launch_bounds__(256)
+gather_field_kernel(Store st, long long count, int first_slot, int width, float *__restrict__ out)
+{
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    long long id = st.ids()[j];
+    for (int k = 0; k < width; k++) out[id * width + k] = st.slot(first_slot + k)[j];
+}
+
+// Halo merge of the slab decomposition: dst.comp += src.comp (wrapping i32).
+__global__ void __launch_bounds__(256)
+plane_add_kernel(int4 *__restrict__ dst, const int4 *__restrict__ src, long long cells,
+                 unsigned mask)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    int4 d = dst[i], s = src[i];
+    if (mask & 1u) d.x = (int)((unsigned)d.x + (unsigned)s.x);
+    if (mask & 2u) d.y = (int)((unsigned)d.y + (unsigned)s.y);
+    if (mask & 4u) d.z = (int)((unsigned)d.z + (unsigned)s.z);
+    if (mask & 8u) d.w = (int)((unsigned)d.w + (unsigned)s.w);
+    dst[i] = d;
+}
+
+}  // namespace mpm

@@ -1,0 +1,508 @@
+// Tiled particle<->grid transfers for CDNA4 (FLOWMPM_ALGO_TILED).
+//
+// Particles are kept grouped ("binned") by the grid tile that contains
+// floor(position).  One workgroup owns one work item = a run of particles of one
+// tile, and keeps that tile plus a one-cell rim (the "arena") in LDS:
+//
+//   p2g1 / p2g2: every stencil contribution is encoded to the reference's
+//     fixed-point i32 FIRST (SIM:279-281) and then summed with LDS integer
+//     atomics; the arena is flushed to the global grid with one i32 atomic per
+//     touched cell component.  Integer addition is associative and wraps, so
+//     the grid is bit-identical to the reference's 27x4 global atomics per
+//     particle, whatever the grouping.
+//   g2p: the float grid of the arena is staged in LDS once and gathered from there.
+//
+// Binning may be stale by a few steps (rebin_interval): a contribution whose
+// cell fell outside the arena goes straight to the global grid, so staleness
+// costs speed, never correctness.
+#pragma once
+
+#include <string>
+
+#include "kernels_migrate.h"
+
+namespace mpm {
+
+// Tile shape in cells.  The arena adds one cell on every side.
+constexpr int kTX = 8, kTY = 8, kTZ = 8;
+constexpr int kAX = kTX + 2, kAY = kTY + 2, kAZ = kTZ + 2;
+constexpr int kArenaCells = kAX * kAY * kAZ;
+constexpr int kArenaPad = kArenaCells + 8;     // component stride in LDS (dwords)
+constexpr int kChunk = 4096;                   // most particles one work item holds
+constexpr int kTiledThreads = 256;
+
+struct TiledState {
+    bool valid = false;
+    int steps_since_rebin = 0;
+    int tiles_x = 0, tiles_y = 0, tiles_z = 0, n_tiles = 0;
+    long long item_cap = 0;
+    int *key = nullptr;          // per slot: tile id
+    int *rank = nullptr;         // per slot: position inside its tile's run
+    int *tile_count = nullptr;   // [n_tiles]
+    int *tile_start = nullptr;   // [n_tiles + 1]
+    int4 *items = nullptr;       // work items {tile, begin, end, 0}
+    int *n_items = nullptr;      // device scalar
+};
+
+struct TileDims { int tiles_x, tiles_y, tiles_z; };
+
+__device__ __forceinline__ int tile_of(float px, float py, float pz, const Params &P, TileDims td)
+{
+    int lx = f32_to_i32(px) - P.x_off, y = f32_to_i32(py), z = f32_to_i32(pz);
+    lx = min(max(lx, 0), P.local_nx - 1);
+    y = min(max(y, 0), P.gy - 1);
+    z = min(max(z, 0), P.gz - 1);
+    return ((lx / kTX) * td.tiles_y + (y / kTY)) * td.tiles_z + (z / kTZ);
+}
+
+// ---- binning -------------------------------------------------------------------
+
+// Pass 1: tile id per particle and its arrival rank inside the tile.  Lanes of a
+// wave that hold the same tile in a row (the common case: the store is nearly
+// sorted already) share ONE atomic on the tile counter.
+__global__ void __launch_bounds__(256)
+bin_count_kernel(Store st, long long n, Params P, TileDims td, int *__restrict__ key,
+                 int *__restrict__ rank, int *__restrict__ tile_count)
+{
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = j < n;
+    int k = -1 - lane;   // distinct for idle lanes, never equal to a tile id
+    if (valid) k = tile_of(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j], P, td);
+    int prev = __shfl_up(k, 1);
+    bool head = (lane == 0) || (k != prev);
+    unsigned long long heads = __ballot(head);
+    unsigned long long upto = (2ULL << lane) - 1ULL;            // bits 0..lane
+    int start = 63 - __clzll((long long)(heads & upto));
+    unsigned long long above = heads & ~upto;
+    int end = above ? (__ffsll((long long)above) - 1) : 64;
+    int base = 0;
+    if (head && valid) base = atomicAdd(&tile_count[k], end - start);
+    base = __shfl(base, start);
+    if (valid) { key[j] = k; rank[j] = base + (lane - start); }
+}
+
+// Pass 2 (one workgroup): exclusive scan of the tile counts into tile_start and
+// the list of work items (runs of at most kChunk particles of one tile).
+__global__ void __launch_bounds__(1024)
+bin_scan_kernel(const int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
+                int4 *__restrict__ items, int *__restrict__ n_items_out, long long item_cap)
+{
+    __shared__ int s_cnt[1024];
+    __shared__ int s_itm[1024];
+    __shared__ int carry_cnt, carry_itm;
+    const int t = threadIdx.x;
+    if (t == 0) { carry_cnt = 0; carry_itm = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        int i = base + t;
+        int c = (i < n_tiles) ? tile_count[i] : 0;
+        int m = (c + kChunk - 1) / kChunk;
+        s_cnt[t] = c; s_itm[t] = m;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {       // Hillis-Steele inclusive scan
+            int a = 0, b = 0;
+            if (t >= off) { a = s_cnt[t - off]; b = s_itm[t - off]; }
+            __syncthreads();
+            s_cnt[t] += a; s_itm[t] += b;
+            __syncthreads();
+        }
+        int start = carry_cnt + s_cnt[t] - c;
+        int first_item = carry_itm + s_itm[t] - m;
+        if (i < n_tiles) {
+            tile_start[i] = start;
+            for (int q = 0; q < m; q++) {
+                if (first_item + q < item_cap)
+                    items[first_item + q] = make_int4(i, start + q * kChunk, min(start + (q + 1) * kChunk, start + c), 0);
+            }
+        }
+        __syncthreads();
+        if (t == 1023) { carry_cnt += s_cnt[t]; carry_itm += s_itm[t]; }
+        __syncthreads();
+    }
+    if (t == 0) { tile_start[n_tiles] = carry_cnt; *n_items_out = carry_itm; }
+}
+
+// Pass 3: move every particle record to its slot in the binned store.
+__global__ void __launch_bounds__(256)
+bin_scatter_kernel(Store src, Store dst, long long n, const int *__restrict__ key,
+                   const int *__restrict__ rank, const int *__restrict__ tile_start)
+{
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    long long d = (long long)tile_start[key[j]] + rank[j];
+#pragma unroll
+    for (int w = 0; w < kRecordWords; w++) dst.slot(w)[d] = src.slot(w)[j];
+}
+
+// ---- arena helpers ---------------------------------------------------------------
+
+struct Arena {
+    int ox, oy, oz;      // global cell coordinates of arena cell (0,0,0)
+};
+
+__device__ __forceinline__ Arena arena_of_tile(int tile, TileDims td, const Params &P)
+{
+    int tz = tile % td.tiles_z;
+    int ty = (tile / td.tiles_z) % td.tiles_y;
+    int tx = tile / (td.tiles_z * td.tiles_y);
+    return Arena{tx * kTX + P.x_off - 1, ty * kTY - 1, tz * kTZ - 1};
+}
+
+__device__ __forceinline__ int arena_index(int ax, int ay, int az) { return (ax * kAY + ay) * kAZ + az; }
+
+// Global (local-grid) linear index of arena cell a, or -1 outside the held planes.
+__device__ __forceinline__ long long arena_cell_to_grid(int a, const Arena &A, const Params &P)
+{
+    int az = a % kAZ, ay = (a / kAZ) % kAY, ax = a / (kAZ * kAY);
+    return local_cell(A.ox + ax, A.oy + ay, A.oz + az, P);
+}
+
+// Adds every non-zero word of an LDS arena component to the global grid.  A wave
+// instruction covers (component, consecutive cells) so that its 64 atomics fall
+// in runs of contiguous 16-byte cell records.
+template <int NCOMP>
+__device__ __forceinline__ void flush_arena(const int *lds, const Arena &A, const Params &P,
+                                            int *__restrict__ cell)
+{
+    for (int f = threadIdx.x; f < kArenaCells * 4; f += kTiledThreads) {
+        int comp = f & 3, a = f >> 2;
+        if (comp >= NCOMP) continue;
+        int v = lds[comp * kArenaPad + a];
+        if (v == 0) continue;
+        long long c = arena_cell_to_grid(a, A, P);
+        if (c >= 0) atomicAdd(cell + 4 * c + comp, v);
+    }
+}
+
+// ---- p2g1 (SIM:295-333) ------------------------------------------------------------
+
+// One particle's 27 x 4 contributions.  INSIDE: the whole stencil lies in the
+// arena and goes to LDS; otherwise (a particle that drifted out of its bin since
+// the last re-bin) it goes straight to the global grid.
+template <bool INSIDE>
+__device__ __forceinline__ void p2g1_particle(const Stencil &s, float vx, float vy, float vz, const float C[9],
+                                              int *lds, int abase, int *__restrict__ cell, const Params &P)
+{
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++) {
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                float dx = s.dx[gx], dy = s.dy[gy], dz = s.dz[gz];
+                float qx = (C[0] * dx + C[3] * dy) + C[6] * dz;
+                float qy = (C[1] * dx + C[4] * dy) + C[7] * dz;
+                float qz = (C[2] * dx + C[5] * dy) + C[8] * dz;
+                int ex = encode_fixed(weight * (vx + qx));
+                int ey = encode_fixed(weight * (vy + qy));
+                int ez = encode_fixed(weight * (vz + qz));
+                int em = encode_fixed(weight);
+                if (INSIDE) {
+                    int a = abase + arena_index(gx, gy, gz);
+                    atomicAdd(&lds[0 * kArenaPad + a], ex);
+                    atomicAdd(&lds[1 * kArenaPad + a], ey);
+                    atomicAdd(&lds[2 * kArenaPad + a], ez);
+                    atomicAdd(&lds[3 * kArenaPad + a], em);
+                } else {
+                    long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                    if (c >= 0) {
+                        atomicAdd(cell + 4 * c + 0, ex);
+                        atomicAdd(cell + 4 * c + 1, ey);
+                        atomicAdd(cell + 4 * c + 2, ez);
+                        atomicAdd(cell + 4 * c + 3, em);
+                    }
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bool stencil_in_arena(const Stencil &s, const Arena &A, int *abase)
+{
+    const int bx = s.cx - A.ox, by = s.cy - A.oy, bz = s.cz - A.oz;   // arena coords of the stencil base
+    *abase = arena_index(bx, by, bz);
+    return (unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
+           (unsigned)bz <= (unsigned)(kAZ - 3);
+}
+
+__global__ void __launch_bounds__(kTiledThreads)
+p2g1_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
+                  TileDims td, int *__restrict__ cell, Params P)
+{
+    if ((int)blockIdx.x >= *n_items) return;
+    __shared__ int lds[4 * kArenaPad];
+    const int4 item = items[blockIdx.x];
+    const Arena A = arena_of_tile(item.x, td, P);
+    for (int i = threadIdx.x; i < 4 * kArenaPad; i += kTiledThreads) lds[i] = 0;
+    __syncthreads();
+
+    for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
+        float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
+        float vx = st.slot(kVelX)[j], vy = st.slot(kVelY)[j], vz = st.slot(kVelZ)[j];
+        float C[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) C[k] = st.slot(kC00 + k)[j];
+        Stencil s = make_stencil(px, py, pz);
+        int abase;
+        if (stencil_in_arena(s, A, &abase))
+            p2g1_particle<true>(s, vx, vy, vz, C, lds, abase, cell, P);
+        else
+            p2g1_particle<false>(s, vx, vy, vz, C, lds, abase, cell, P);
+    }
+    __syncthreads();
+    flush_arena<4>(lds, A, P, cell);
+}
+
+// ---- p2g2 (SIM:336-392) ------------------------------------------------------------
+
+template <bool INSIDE>
+__device__ __forceinline__ void p2g2_particle(const Stencil &s, const float C[9], float *dens_slot, int *lds,
+                                              const float *mass_f, int abase, int *__restrict__ cell,
+                                              const Params &P)
+{
+    float density = 0.0f;
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                float m;
+                if (INSIDE) {
+                    m = mass_f[abase + arena_index(gx, gy, gz)];
+                } else {
+                    long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                    m = decode_fixed((c >= 0) ? cell[4 * c + 3] : 0);
+                }
+                density = density + m * weight;
+            }
+        }
+    *dens_slot = *dens_slot * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
+    Eq16 e = p2g2_stress(density, C, P);
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                float dx = s.dx[gx], dy = s.dy[gy], dz = s.dz[gz];
+                float a00 = e.m00 * weight, a11 = e.m11 * weight, a22 = e.m22 * weight;
+                float a01 = e.m01 * weight, a02 = e.m02 * weight, a12 = e.m12 * weight;
+                int ex = encode_fixed((a00 * dx + a01 * dy) + a02 * dz);
+                int ey = encode_fixed((a01 * dx + a11 * dy) + a12 * dz);
+                int ez = encode_fixed((a02 * dx + a12 * dy) + a22 * dz);
+                if (INSIDE) {
+                    int a = abase + arena_index(gx, gy, gz);
+                    atomicAdd(&lds[0 * kArenaPad + a], ex);
+                    atomicAdd(&lds[1 * kArenaPad + a], ey);
+                    atomicAdd(&lds[2 * kArenaPad + a], ez);
+                } else {
+                    long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                    if (c >= 0) {
+                        atomicAdd(cell + 4 * c + 0, ex);
+                        atomicAdd(cell + 4 * c + 1, ey);
+                        atomicAdd(cell + 4 * c + 2, ez);
+                    }
+                }
+            }
+        }
+}
+
+__global__ void __launch_bounds__(kTiledThreads)
+p2g2_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
+                  TileDims td, int *__restrict__ cell, Params P)
+{
+    if ((int)blockIdx.x >= *n_items) return;
+    __shared__ int lds[3 * kArenaPad];
+    __shared__ float mass_f[kArenaCells];      // decodeFixedPoint(cell.mass), once per arena cell
+    const int4 item = items[blockIdx.x];
+    const Arena A = arena_of_tile(item.x, td, P);
+    for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
+    for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
+        long long c = arena_cell_to_grid(a, A, P);
+        int m = (c >= 0) ? cell[4 * c + 3] : 0;
+        mass_f[a] = decode_fixed(m);
+    }
+    __syncthreads();
+
+    float *dens = st.slot(kDensity);
+    for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
+        float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
+        float C[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) C[k] = st.slot(kC00 + k)[j];
+        Stencil s = make_stencil(px, py, pz);
+        int abase;
+        if (stencil_in_arena(s, A, &abase))
+            p2g2_particle<true>(s, C, dens + j, lds, mass_f, abase, cell, P);
+        else
+            p2g2_particle<false>(s, C, dens + j, lds, mass_f, abase, cell, P);
+    }
+    __syncthreads();
+    flush_arena<3>(lds, A, P, cell);
+}
+
+// ---- g2p (SIM:431-1536, chaos path) -----------------------------------------------
+
+template <bool INSIDE>
+__device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid, int abase,
+                                           const float4 *__restrict__ cellf, const Params &P, Vec3 &v, float B[9])
+{
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                float4 f;
+                if (INSIDE) {
+                    f = grid[abase + arena_index(gx, gy, gz)];
+                } else {
+                    long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                    f = (c >= 0) ? cellf[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                float wvx = f.x * weight, wvy = f.y * weight, wvz = f.z * weight;
+                float dx = s.dx[gx], dy = s.dy[gy], dz = s.dz[gz];
+                B[0] = B[0] + wvx * dx; B[1] = B[1] + wvy * dx; B[2] = B[2] + wvz * dx;
+                B[3] = B[3] + wvx * dy; B[4] = B[4] + wvy * dy; B[5] = B[5] + wvz * dy;
+                B[6] = B[6] + wvx * dz; B[7] = B[7] + wvy * dz; B[8] = B[8] + wvz * dz;
+                v.x = v.x + wvx; v.y = v.y + wvy; v.z = v.z + wvz;
+            }
+        }
+}
+
+__global__ void __launch_bounds__(kTiledThreads)
+g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
+                 TileDims td, const float4 *__restrict__ cellf, Params P)
+{
+    if ((int)blockIdx.x >= *n_items) return;
+    __shared__ float4 grid[kArenaCells];
+    const int4 item = items[blockIdx.x];
+    const Arena A = arena_of_tile(item.x, td, P);
+    for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
+        long long c = arena_cell_to_grid(a, A, P);
+        grid[a] = (c >= 0) ? cellf[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+
+    for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
+        G2PIn in;
+        in.px = st.slot(kPosX)[j]; in.py = st.slot(kPosY)[j]; in.pz = st.slot(kPosZ)[j];
+        in.mass = st.slot(kMass)[j];
+        in.dirx = st.slot(kDirX)[j]; in.diry = st.slot(kDirY)[j]; in.dirz = st.slot(kDirZ)[j];
+        Vec3 v = g2p_pre_forces(in.px, in.py, in.pz, P);
+        Stencil s = make_stencil(in.px, in.py, in.pz);
+        float B[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) B[k] = 0.0f;
+        int abase;
+        if (stencil_in_arena(s, A, &abase))
+            g2p_gather<true>(s, grid, abase, cellf, P, v, B);
+        else
+            g2p_gather<false>(s, grid, abase, cellf, P, v, B);
+        G2POut o = g2p_finish(in, v, B, P);
+#pragma unroll
+        for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
+        st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;
+        st.slot(kVelX)[j] = o.vx; st.slot(kVelY)[j] = o.vy; st.slot(kVelZ)[j] = o.vz;
+        st.slot(kDirX)[j] = o.dirx; st.slot(kDirY)[j] = o.diry; st.slot(kDirZ)[j] = o.dirz;
+    }
+}
+
+// ---- host side -------------------------------------------------------------------
+
+inline TileDims tile_dims(const TiledState &T) { return TileDims{T.tiles_x, T.tiles_y, T.tiles_z}; }
+
+inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStream_t stream, std::string *msg)
+{
+    T.tiles_x = (P.local_nx + kTX - 1) / kTX;
+    T.tiles_y = (P.gy + kTY - 1) / kTY;
+    T.tiles_z = (P.gz + kTZ - 1) / kTZ;
+    T.n_tiles = T.tiles_x * T.tiles_y * T.tiles_z;
+    T.item_cap = (long long)T.n_tiles + capacity / kChunk + 1;
+    hipError_t e;
+    auto chk = [&](hipError_t err, const char *what) {
+        if (err != hipSuccess) { *msg = std::string(what) + ": " + hipGetErrorString(err); return true; }
+        return false;
+    };
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.key), (size_t)capacity * sizeof(int)), "hipMalloc key")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.rank), (size_t)capacity * sizeof(int)), "hipMalloc rank")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.tile_count), (size_t)T.n_tiles * sizeof(int)), "hipMalloc tile_count")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.tile_start), (size_t)(T.n_tiles + 1) * sizeof(int)), "hipMalloc tile_start")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.items), (size_t)T.item_cap * sizeof(int4)), "hipMalloc items")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.n_items), sizeof(int)), "hipMalloc n_items")) return 1;
+    if (chk(e = hipMemsetAsync(T.n_items, 0, sizeof(int), stream), "memset n_items")) return 1;
+    T.valid = false;
+    T.steps_since_rebin = 0;
+    return 0;
+}
+
+inline void tiled_free(TiledState &T)
+{
+    if (T.key) (void)hipFree(T.key);
+    if (T.rank) (void)hipFree(T.rank);
+    if (T.tile_count) (void)hipFree(T.tile_count);
+    if (T.tile_start) (void)hipFree(T.tile_start);
+    if (T.items) (void)hipFree(T.items);
+    if (T.n_items) (void)hipFree(T.n_items);
+    T = TiledState{};
+}
+
+// Groups the first n particles of `src` by tile into `dst` and rebuilds the work items.
+inline int rebin(TiledState &T, Store src, Store dst, long long n, const Params &P, hipStream_t stream,
+                 std::string *msg)
+{
+    hipError_t e = hipMemsetAsync(T.tile_count, 0, (size_t)T.n_tiles * sizeof(int), stream);
+    if (e != hipSuccess) { *msg = std::string("memset tile_count: ") + hipGetErrorString(e); return 1; }
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    const TileDims td = tile_dims(T);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(blocks), dim3(256), 0, stream, src, n, P, td, T.key, T.rank, T.tile_count);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, stream, T.tile_count, T.n_tiles, T.tile_start,
+                       T.items, T.n_items, T.item_cap);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n, T.key, T.rank, T.tile_start);
+    e = hipGetLastError();
+    if (e != hipSuccess) { *msg = std::string("rebin launch: ") + hipGetErrorString(e); return 1; }
+    T.valid = true;
+    T.steps_since_rebin = 0;
+    return 0;
+}
+
+// Upper bound of the work items any binning of n particles can produce.
+inline unsigned item_bound(const TiledState &T, long long n)
+{
+    long long b = std::min<long long>(T.item_cap, std::min<long long>((long long)T.n_tiles, n) + n / kChunk + 1);
+    return (unsigned)std::max<long long>(b, 1);
+}
+
+inline int launch_p2g1_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P, hipStream_t stream)
+{
+    hipLaunchKernelGGL(p2g1_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
+                       T.n_items, tile_dims(T), reinterpret_cast<int *>(cell), P);
+    return 0;
+}
+
+inline int launch_p2g2_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P, hipStream_t stream)
+{
+    hipLaunchKernelGGL(p2g2_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
+                       T.n_items, tile_dims(T), reinterpret_cast<int *>(cell), P);
+    return 0;
+}
+
+inline int launch_g2p_tiled(TiledState &T, Store st, long long n, const float4 *cellf, const Params &P,
+                            hipStream_t stream)
+{
+    hipLaunchKernelGGL(g2p_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
+                       T.n_items, tile_dims(T), cellf, P);
+    return 0;
+}
+
+}  // namespace mpm

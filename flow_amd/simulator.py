@@ -1,0 +1,361 @@
+"""Host side of the MLS-MPM simulator: the reference's class surface over the HIP library.
+
+`MlsMpmSimulator` mirrors the parts of the reference class that sit on the hot path
+(src/mls-mpm/mlsMpmSimulator.js, "SIM"): the constructor (SIM:71-73), init()
+(SIM:74-260), update(interval, elapsed) (SIM:2423-2541) and setMouseRay (SIM:1539-1546),
+with the same field names (`numParticles`, `gridSize`, `uniforms.<name>.value`,
+`fixedPointMultiplier`, `particleBuffer`).  Where the reference hands five kernels to
+three.js (SIM:2538-2539) this class calls the C ABI of include/flowmpm.h.
+
+`Handle` is the thin object wrapper over that C ABI which tests and the benchmark
+use directly.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib
+from .conf import conf as default_conf
+from .particles import reference_scene
+from .structured_array import PARTICLE_STRUCT, StructuredArray
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+class Handle:
+    """One flowmpm_sim.  Every method maps to one C entry point."""
+
+    def __init__(self, grid, max_particles, device=0, algorithm=_lib.ALGO_TILED, rebin_interval=1,
+                 slab=None, stream=None):
+        self.L = _lib.load()
+        cfg = _lib.Config()
+        cfg.grid_x, cfg.grid_y, cfg.grid_z = (int(g) for g in grid)
+        cfg.slab_x0, cfg.slab_nx = (int(slab[0]), int(slab[1])) if slab else (0, 0)
+        cfg.device = int(device)
+        cfg.algorithm = int(algorithm)
+        cfg.rebin_interval = int(rebin_interval)
+        cfg.max_particles = int(max_particles)
+        cfg.stream = stream
+        self.grid = (cfg.grid_x, cfg.grid_y, cfg.grid_z)
+        self.max_particles = int(max_particles)
+        self.slab = slab
+        self._h = ctypes.c_void_p()
+        _lib.check(None, self.L.flowmpm_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.flowmpm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, code):
+        _lib.check(self._h, code)
+
+    def upload_particles(self, records, ids=None):
+        rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, _lib.PARTICLE_STRIDE)
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.int32)
+            assert ids.shape[0] == rec.shape[0]
+            idp = _ip(ids)
+        self._chk(self.L.flowmpm_upload_particles(self._h, _fp(rec), idp, rec.shape[0]))
+
+    def set_num_particles(self, n):
+        self._chk(self.L.flowmpm_set_num_particles(self._h, int(n)))
+
+    def num_particles(self):
+        live, resident = ctypes.c_int64(), ctypes.c_int64()
+        self._chk(self.L.flowmpm_get_num_particles(self._h, ctypes.byref(live), ctypes.byref(resident)))
+        return live.value, resident.value
+
+    def set_uniforms(self, dt=0.1, stiffness=3.0, rest_density=2.5, dynamic_viscosity=0.1, noise=1.0,
+                     time=0.0, mouse_ray_direction=(0.0, 0.0, 0.0), mouse_ray_origin=(0.0, 0.0, 0.0),
+                     mouse_force=(0.0, 0.0, 0.0), cursor_interaction=0, hide_percentage=0.0,
+                     grid_mode=0, front_gravity_mode=0):
+        u = _lib.Uniforms()
+        u.dt, u.stiffness, u.rest_density = dt, stiffness, rest_density
+        u.dynamic_viscosity, u.noise, u.time = dynamic_viscosity, noise, time
+        u.mouse_ray_direction[:] = mouse_ray_direction
+        u.mouse_ray_origin[:] = mouse_ray_origin
+        u.mouse_force[:] = mouse_force
+        u.cursor_interaction = int(cursor_interaction)
+        u.hide_percentage = hide_percentage
+        u.grid_mode, u.front_gravity_mode = int(grid_mode), int(front_gravity_mode)
+        self._chk(self.L.flowmpm_set_uniforms(self._h, ctypes.byref(u)))
+
+    def step(self, n_steps=1, dtime=0.0):
+        self._chk(self.L.flowmpm_step(self._h, int(n_steps), float(dtime)))
+
+    def run_kernel(self, kernel_id):
+        self._chk(self.L.flowmpm_run_kernel(self._h, int(kernel_id)))
+
+    def synchronize(self):
+        self._chk(self.L.flowmpm_synchronize(self._h))
+
+    def download_particles(self):
+        """Records in particle-id order (single GPU), or (records, ids) for a slab."""
+        _, resident = self.num_particles()
+        rec = np.zeros((max(resident, 1), _lib.PARTICLE_STRIDE), dtype=np.float32)
+        ids = np.zeros(max(resident, 1), dtype=np.int32)
+        count = ctypes.c_int64()
+        self._chk(self.L.flowmpm_download_particles(self._h, _fp(rec), _ip(ids), rec.shape[0],
+                                                    ctypes.byref(count)))
+        if self.slab:
+            return rec[:count.value], ids[:count.value]
+        return rec[:count.value]
+
+    def download_field(self, field):
+        live, _ = self.num_particles()
+        out = np.zeros((max(live, 1), _lib.FIELD_WIDTH[field]), dtype=np.float32)
+        self._chk(self.L.flowmpm_download_field(self._h, int(field), _fp(out), out.shape[0]))
+        return out[:live]
+
+    def local_grid(self):
+        x0, nx = ctypes.c_int32(), ctypes.c_int32()
+        self._chk(self.L.flowmpm_get_local_grid(self._h, ctypes.byref(x0), ctypes.byref(nx)))
+        return x0.value, nx.value
+
+    def download_grid_i32(self):
+        _, nx = self.local_grid()
+        cells = nx * self.grid[1] * self.grid[2]
+        out = np.zeros((cells, 4), dtype=np.int32)
+        self._chk(self.L.flowmpm_download_grid_i32(self._h, _ip(out), cells))
+        return out
+
+    def download_grid_f32(self):
+        _, nx = self.local_grid()
+        cells = nx * self.grid[1] * self.grid[2]
+        out = np.zeros((cells, 4), dtype=np.float32)
+        self._chk(self.L.flowmpm_download_grid_f32(self._h, _fp(out), cells))
+        return out
+
+    def set_profiling(self, enabled):
+        self._chk(self.L.flowmpm_set_profiling(self._h, 1 if enabled else 0))
+
+    def reset_timings(self):
+        self._chk(self.L.flowmpm_reset_timings(self._h))
+
+    def timings(self):
+        t = _lib.Timings()
+        self._chk(self.L.flowmpm_get_timings(self._h, ctypes.byref(t)))
+        names = list(_lib.KERNEL_NAMES) + ["rebin"]
+        return {names[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(len(names))}
+
+    # ---- slab decomposition ----
+    def plane_ptr(self, plane):
+        p, nbytes = ctypes.c_void_p(), ctypes.c_int64()
+        self._chk(self.L.flowmpm_plane_ptr(self._h, int(plane), ctypes.byref(p), ctypes.byref(nbytes)))
+        return p.value, nbytes.value
+
+    def plane_add_i32(self, plane, dev_src, comp_mask):
+        self._chk(self.L.flowmpm_plane_add_i32(self._h, int(plane), ctypes.c_void_p(dev_src), int(comp_mask)))
+
+    def plane_copy_out(self, plane, dev_dst):
+        self._chk(self.L.flowmpm_plane_copy_out(self._h, int(plane), ctypes.c_void_p(dev_dst)))
+
+    def extract_leavers(self, plane_starts, dev_out, capacity_records):
+        starts = np.ascontiguousarray(plane_starts, dtype=np.int32)
+        n_ranks = starts.shape[0] - 1
+        counts = np.zeros(n_ranks, dtype=np.int64)
+        self._chk(self.L.flowmpm_extract_leavers(
+            self._h, _ip(starts), n_ranks, ctypes.c_void_p(dev_out), int(capacity_records),
+            counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        return counts
+
+    def insert_arrivals(self, dev_in, count):
+        self._chk(self.L.flowmpm_insert_arrivals(self._h, ctypes.c_void_p(dev_in), int(count)))
+
+
+class Vector3:
+    """The few three.js Vector3 operations the simulator's host code uses
+    (setMouseRay mutates its arguments, SIM:1540-1545)."""
+
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        self.x, self.y, self.z = float(x), float(y), float(z)
+
+    def set(self, x, y, z):
+        self.x, self.y, self.z = float(x), float(y), float(z)
+        return self
+
+    def copy(self, v):
+        self.x, self.y, self.z = v.x, v.y, v.z
+        return self
+
+    def clone(self):
+        return Vector3(self.x, self.y, self.z)
+
+    def add(self, v):
+        self.x += v.x; self.y += v.y; self.z += v.z
+        return self
+
+    def sub(self, v):
+        self.x -= v.x; self.y -= v.y; self.z -= v.z
+        return self
+
+    def multiplyScalar(self, s):
+        self.x *= s; self.y *= s; self.z *= s
+        return self
+
+    def divideScalar(self, s):
+        return self.multiplyScalar(1 / s)
+
+    def length(self):
+        return math.sqrt(self.x * self.x + self.y * self.y + self.z * self.z)
+
+    def normalize(self):
+        return self.divideScalar(self.length() or 1)
+
+    def toArray(self):
+        return [self.x, self.y, self.z]
+
+
+class Uniform:
+    """`uniforms.<name>.value`, as three.js's uniform() nodes expose it."""
+
+    def __init__(self, value):
+        self.value = value
+
+
+class _Uniforms:
+    pass
+
+
+class MlsMpmSimulator:
+    fixedPointMultiplier = 1e7          # SIM:43
+
+    def __init__(self, renderer=None, conf=None, device=0, algorithm=_lib.ALGO_TILED, rebin_interval=4,
+                 seed=0xF10E5EED):
+        self.renderer = renderer         # kept for signature parity; unused (SIM:71-73)
+        self.conf = conf if conf is not None else default_conf
+        self.device = device
+        self.algorithm = algorithm
+        self.rebin_interval = rebin_interval
+        self.seed = seed
+        self.numParticles = 0
+        self.gridSize = Vector3(0, 0, 0)
+        self.uniforms = _Uniforms()
+        self.mousePos = Vector3()
+        self.mousePosArray = []
+        self.particleBuffer = None
+        self.handle = None
+
+    def init(self):
+        """SIM:74-260: grid size, particle records, grids, uniforms."""
+        max_particles = self.conf.maxParticles
+        self.gridSize.set(128, 64, 64)                                   # SIM:76
+        grid = (128, 64, 64)
+        self.particleBuffer = StructuredArray(PARTICLE_STRUCT, max_particles, "particleData")
+        self.particleBuffer.records()[:] = reference_scene(max_particles, grid, self.seed)  # SIM:114-129
+        u = self.uniforms
+        u.gravityType = Uniform(0)
+        u.gravity = Uniform(Vector3())
+        u.stiffness = Uniform(0.0)
+        u.restDensity = Uniform(0.0)
+        u.dynamicViscosity = Uniform(0.0)
+        u.noise = Uniform(0.0)
+        u.gridSize = Uniform(self.gridSize)
+        u.dt = Uniform(0.1)
+        u.numParticles = Uniform(0)
+        u.gridMode = Uniform(0)
+        u.frontGravityMode = Uniform(0)
+        u.mouseRayDirection = Uniform(Vector3())
+        u.mouseRayOrigin = Uniform(Vector3())
+        u.mouseForce = Uniform(Vector3())
+        u.cursorInteraction = Uniform(0)
+        u.hidePercentage = Uniform(0.0)
+        u.time = Uniform(0.0)            # three.js TSL `time` node (SIM:22, 1318)
+        self.handle = Handle(grid, max_particles, device=self.device, algorithm=self.algorithm,
+                             rebin_interval=self.rebin_interval)
+        self.handle.upload_particles(self.particleBuffer.records())
+        return self
+
+    def setMouseRay(self, origin, direction, pos):
+        """SIM:1539-1546.  Mutates `origin`, `direction` and `pos` like the reference."""
+        origin.multiplyScalar(64)
+        pos.multiplyScalar(64)
+        origin.add(Vector3(64, 0, 0))
+        self.uniforms.mouseRayDirection.value.copy(direction.normalize())
+        self.uniforms.mouseRayOrigin.value.copy(origin)
+        self.mousePos.copy(pos)
+
+    def update(self, interval, elapsed):
+        """SIM:2423-2541: one frame = one step.  `elapsed` supplies the clock that the
+        reference's noise reads from three.js's `time` node."""
+        c = self.conf
+        u = self.uniforms
+        u.noise.value = c.noise                                          # SIM:2496-2511
+        u.stiffness.value = c.stiffness
+        u.gravityType.value = c.gravity
+        u.gravity.value.set(0, 0, 0)
+        u.cursorInteraction.value = 1 if c.cursorInteraction else 0
+        u.hidePercentage.value = c.hidePercentage
+        u.dynamicViscosity.value = c.dynamicViscosity
+        u.restDensity.value = c.restDensity
+        u.time.value = elapsed
+
+        if c.particles != self.numParticles:                             # SIM:2513-2522
+            self.numParticles = c.particles
+            u.numParticles.value = c.particles
+            self.handle.set_num_particles(c.particles)
+
+        interval = min(interval, 1 / 60)                                 # SIM:2524-2528
+        effective_speed = 4.0 if u.frontGravityMode.value == 1 else c.speed
+        u.dt.value = interval * 6 * effective_speed
+
+        self.mousePosArray.append(self.mousePos.clone())                 # SIM:2530-2534
+        if len(self.mousePosArray) > 3:
+            self.mousePosArray.pop(0)
+        if len(self.mousePosArray) > 1:
+            u.mouseForce.value.copy(self.mousePosArray[-1]).sub(self.mousePosArray[0]) \
+                .divideScalar(len(self.mousePosArray))
+
+        if c.run:                                                        # SIM:2537-2540
+            self._push_uniforms()
+            self.handle.step(1, 0.0)
+
+    def _push_uniforms(self):
+        u = self.uniforms
+        self.handle.set_uniforms(
+            dt=u.dt.value, stiffness=u.stiffness.value, rest_density=u.restDensity.value,
+            dynamic_viscosity=u.dynamicViscosity.value, noise=u.noise.value, time=u.time.value,
+            mouse_ray_direction=u.mouseRayDirection.value.toArray(),
+            mouse_ray_origin=u.mouseRayOrigin.value.toArray(),
+            mouse_force=u.mouseForce.value.toArray(),
+            cursor_interaction=u.cursorInteraction.value, hide_percentage=u.hidePercentage.value,
+            grid_mode=u.gridMode.value, front_gravity_mode=u.frontGravityMode.value)
+
+    # ---- what the reference's renderers bind (particleRenderer.js:119-133,
+    # pointRenderer.js:17-19), as host arrays in particle-id order ----
+    def getPositions(self):
+        return self.handle.download_field(_lib.FIELD_POSITION)
+
+    def getVelocities(self):
+        return self.handle.download_field(_lib.FIELD_VELOCITY)
+
+    def getDensities(self):
+        return self.handle.download_field(_lib.FIELD_DENSITY)
+
+    def getColors(self):
+        return self.handle.download_field(_lib.FIELD_COLOR)
+
+    def readAoS(self):
+        """All maxParticles records in the reference's 28-float layout; also refreshes
+        particleBuffer.floatArray."""
+        rec = self.handle.download_particles()
+        self.particleBuffer.records()[:rec.shape[0]] = rec
+        return rec
+
+    def synchronize(self):
+        self.handle.synchronize()

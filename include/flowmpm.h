@@ -1,0 +1,193 @@
+/*
+ * flowmpm -- C ABI of the MI355X-native MLS-MPM step for noahschwad/flow.
+ *
+ * The reference has no FFI: its simulator is a JavaScript class whose five
+ * compute kernels are handed to three.js (src/mls-mpm/mlsMpmSimulator.js:2538-2539,
+ * `renderer.computeAsync([clearGrid, p2g1, p2g2, updateGrid, g2p])`).  This header
+ * is the boundary a host binding (Node-API addon, ctypes, cgo ...) attaches to in
+ * place of that call.  Each entry point cites the reference code it replaces;
+ * paths are relative to the reference tree and SIM abbreviates
+ * src/mls-mpm/mlsMpmSimulator.js.
+ *
+ * Conventions: every function returns an int status (FLOWMPM_OK = 0); no C++
+ * exception crosses the boundary; `flowmpm_last_error` returns the message of the
+ * most recent failure on a handle.  Host arrays are caller-owned and copied.  A
+ * handle is not thread-safe.  All work of a handle is enqueued on one HIP stream.
+ */
+#ifndef FLOWMPM_H
+#define FLOWMPM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLOWMPM_OK               0
+#define FLOWMPM_ERR_INVALID      1   /* bad argument or call order */
+#define FLOWMPM_ERR_HIP          2   /* HIP runtime failure (message has the HIP error) */
+#define FLOWMPM_ERR_UNSUPPORTED  3   /* a reference mode this library does not implement */
+#define FLOWMPM_ERR_CAPACITY     4   /* more particles than the handle was created for */
+
+/* Particle record the host exchanges with the library: the reference's AoS layout,
+ * 28 floats (src/mls-mpm/structuredArray.js:83-119 applied to SIM:78-86).
+ * Float offsets: position 0-2, density 3, velocity 4-6, mass 7,
+ * C[col][row] at 8 + 4*col + row, direction 20-22, color 24-26; 23 and 27 are pad. */
+#define FLOWMPM_PARTICLE_STRIDE 28
+
+/* Kernel ids for flowmpm_run_kernel, in the reference's submission order (SIM:2538). */
+#define FLOWMPM_KERNEL_CLEAR_GRID   0   /* SIM:262-277  */
+#define FLOWMPM_KERNEL_P2G1         1   /* SIM:295-333  */
+#define FLOWMPM_KERNEL_P2G2         2   /* SIM:336-392  */
+#define FLOWMPM_KERNEL_UPDATE_GRID  3   /* SIM:395-429  */
+#define FLOWMPM_KERNEL_G2P          4   /* SIM:431-1536 (chaos path) */
+#define FLOWMPM_KERNEL_COUNT        5
+
+/* Timing slots reported by flowmpm_get_timings: the five kernels, then the
+ * particle re-binning pass of the tiled algorithm (no reference counterpart). */
+#define FLOWMPM_TIMING_REBIN        5
+#define FLOWMPM_TIMING_SLOTS        8
+
+/* How the particle-to-grid scatter is organised. */
+#define FLOWMPM_ALGO_SCATTER 0   /* the reference's algorithm: one thread per particle,
+                                    27 x 4 global i32 atomics (SIM:315-331) */
+#define FLOWMPM_ALGO_TILED   1   /* particles binned by grid tile, contributions summed
+                                    as fixed-point integers in LDS, one flush per tile */
+
+/* Per-particle fields for flowmpm_download_field (what the reference's renderers
+ * read from the particle buffer: src/mls-mpm/particleRenderer.js:119-133,
+ * src/mls-mpm/pointRenderer.js:17-19, plus velocity/direction). */
+#define FLOWMPM_FIELD_POSITION  0   /* 3 floats */
+#define FLOWMPM_FIELD_VELOCITY  1   /* 3 floats */
+#define FLOWMPM_FIELD_DENSITY   2   /* 1 float  */
+#define FLOWMPM_FIELD_COLOR     3   /* 3 floats */
+#define FLOWMPM_FIELD_DIRECTION 4   /* 3 floats */
+#define FLOWMPM_FIELD_MASS      5   /* 1 float  */
+
+/* Boundary planes of a slab's local grid for the halo exchange. */
+#define FLOWMPM_PLANE_LOW_HALO    0  /* global x = slab_x0 - 1          */
+#define FLOWMPM_PLANE_LOW_OWNED   1  /* global x = slab_x0              */
+#define FLOWMPM_PLANE_HIGH_OWNED  2  /* global x = slab_x0 + slab_nx - 1 */
+#define FLOWMPM_PLANE_HIGH_HALO   3  /* global x = slab_x0 + slab_nx     */
+
+/* Component masks for flowmpm_plane_add_i32. */
+#define FLOWMPM_COMP_MOMENTUM 0x7
+#define FLOWMPM_COMP_MASS     0x8
+#define FLOWMPM_COMP_ALL      0xF
+
+typedef struct flowmpm_sim flowmpm_sim;
+
+/* Replaces the allocations of init() (SIM:74-139): gridSize, the particle buffer of
+ * `max_particles` records and the two grids. */
+typedef struct {
+    int32_t grid_x, grid_y, grid_z;   /* uniforms.gridSize, SIM:76, 148 (global grid) */
+    int32_t slab_x0, slab_nx;         /* x-planes this handle owns; slab_nx = 0 means the
+                                         whole grid (single GPU) */
+    int32_t device;                   /* HIP device ordinal */
+    int32_t algorithm;                /* FLOWMPM_ALGO_* */
+    int32_t rebin_interval;           /* tiled: re-bin particles every k steps (>= 1) */
+    int64_t max_particles;            /* conf.maxParticles, src/conf.js:8 */
+    void   *stream;                   /* hipStream_t to enqueue on, or NULL for a
+                                         stream owned by the handle */
+} flowmpm_config;
+
+/* The uniforms the hot path reads (SIM:141-151, 256-260) plus the clock that
+ * three.js supplies through its TSL `time` node (SIM:22, 1318). */
+typedef struct {
+    float dt;                         /* SIM:150, 2524-2528 */
+    float stiffness;                  /* SIM:143 */
+    float rest_density;               /* SIM:144 */
+    float dynamic_viscosity;          /* SIM:145 */
+    float noise;                      /* SIM:146 */
+    float time;                       /* TSL time node */
+    float mouse_ray_direction[3];     /* SIM:256, 1543 */
+    float mouse_ray_origin[3];        /* SIM:257, 1544 */
+    float mouse_force[3];             /* SIM:258, 2533 */
+    uint32_t cursor_interaction;      /* SIM:259 */
+    float hide_percentage;            /* SIM:260; must be 0 */
+    uint32_t grid_mode;               /* SIM:152; must be 0 */
+    uint32_t front_gravity_mode;      /* SIM:153; must be 0 */
+} flowmpm_uniforms;
+
+typedef struct {
+    double  ms[FLOWMPM_TIMING_SLOTS];        /* summed HIP-event time per slot */
+    int64_t launches[FLOWMPM_TIMING_SLOTS];  /* how many timed launches per slot */
+} flowmpm_timings;
+
+/* Library version and the number of visible HIP devices (fails when no GPU). */
+int flowmpm_version(void);
+int flowmpm_device_count(int *count);
+
+/* init(): SIM:74-139. */
+int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out);
+int flowmpm_destroy(flowmpm_sim *sim);
+const char *flowmpm_last_error(const flowmpm_sim *sim);   /* sim may be NULL: last
+                                                             create/global failure */
+
+/* Replaces three.js's first upload of particleBuffer.floatArray (SIM:87, 126-128) and
+ * the forced re-upload after a mode switch (SIM:2340-2366).  `aos` holds `count`
+ * records; record i becomes particle id i.  In a slab handle only the caller's
+ * particles for that slab are passed, with their global ids in `ids` (NULL: 0..count-1). */
+int flowmpm_upload_particles(flowmpm_sim *sim, const float *aos, const int32_t *ids,
+                             int64_t count);
+/* uniforms.numParticles / dispatch counts (SIM:2513-2522): simulate the first
+ * `count` particle ids only.  Single-GPU handles only. */
+int flowmpm_set_num_particles(flowmpm_sim *sim, int64_t count);
+int flowmpm_get_num_particles(flowmpm_sim *sim, int64_t *live, int64_t *resident);
+
+/* The uniform writes of update() (SIM:2496-2534). */
+int flowmpm_set_uniforms(flowmpm_sim *sim, const flowmpm_uniforms *u);
+
+/* renderer.computeAsync([...5 kernels]) (SIM:2538-2539), `n_steps` times.  The clock
+ * of step k is (float)(uniforms.time + k * dtime).  Asynchronous: returns after
+ * enqueueing; flowmpm_synchronize or any download waits. */
+int flowmpm_step(flowmpm_sim *sim, int32_t n_steps, double dtime);
+/* One of the five kernels alone, for parity tests against the reference's kernels. */
+int flowmpm_run_kernel(flowmpm_sim *sim, int32_t kernel_id);
+int flowmpm_synchronize(flowmpm_sim *sim);
+
+/* Read-back.  The reference never reads back; its renderers bind the storage buffer
+ * (src/mls-mpm/particleRenderer.js:126-133).  A host renderer or a parity dump uses
+ * these.  Particles come back in particle-id order.  A slab handle returns its
+ * resident particles in unspecified order together with their global ids. */
+int flowmpm_download_particles(flowmpm_sim *sim, float *aos, int32_t *ids, int64_t capacity,
+                               int64_t *count);
+int flowmpm_download_field(flowmpm_sim *sim, int32_t field, float *out, int64_t capacity);
+/* cellBuffer (SIM:131-138): 4 x i32 per cell {x, y, z, mass}; cellBufferF (SIM:139):
+ * vec4 {vx, vy, vz, mass}.  Local planes of the handle, x-major (SIM:286-290). */
+int flowmpm_get_local_grid(flowmpm_sim *sim, int32_t *x_first, int32_t *x_planes);
+int flowmpm_download_grid_i32(flowmpm_sim *sim, int32_t *out, int64_t capacity_cells);
+int flowmpm_download_grid_f32(flowmpm_sim *sim, float *out, int64_t capacity_cells);
+
+/* Per-kernel device timing with HIP events on the handle's stream. */
+int flowmpm_set_profiling(flowmpm_sim *sim, int32_t enabled);
+int flowmpm_get_timings(flowmpm_sim *sim, flowmpm_timings *out);
+int flowmpm_reset_timings(flowmpm_sim *sim);
+
+/* ---- Slab decomposition (no reference counterpart: the reference is single-GPU).
+ * The caller owns the transport (RCCL through torch.distributed); these expose the
+ * device-side pieces.  Device pointers returned here stay valid until destroy. ---- */
+
+/* Device address and byte size of one boundary plane of the i32 grid. */
+int flowmpm_plane_ptr(flowmpm_sim *sim, int32_t plane, void **dev_ptr, int64_t *bytes);
+/* grid[plane].comp += src.comp for the components in `comp_mask`, as wrapping i32 adds;
+ * `dev_src` is a device buffer holding one plane in the grid's own layout. */
+int flowmpm_plane_add_i32(flowmpm_sim *sim, int32_t plane, const void *dev_src,
+                          uint32_t comp_mask);
+/* Copies one boundary plane into a caller's device buffer (send staging). */
+int flowmpm_plane_copy_out(flowmpm_sim *sim, int32_t plane, void *dev_dst);
+/* Splits the resident particles after g2p: those whose floor(position.x) left
+ * [slab_x0, slab_x0 + slab_nx) are removed from the handle and written as packed
+ * records (FLOWMPM_MIGRATE_WORDS 32-bit words each: the 23 fields, then the id) into
+ * `dev_out`, grouped by destination rank under the equal-width split given by
+ * `plane_starts[0..n_ranks]`.  counts[r] receives the number bound for rank r. */
+#define FLOWMPM_MIGRATE_WORDS 24
+int flowmpm_extract_leavers(flowmpm_sim *sim, const int32_t *plane_starts, int32_t n_ranks,
+                            void *dev_out, int64_t capacity_records, int64_t *counts);
+/* Appends packed records that arrived from other ranks. */
+int flowmpm_insert_arrivals(flowmpm_sim *sim, const void *dev_in, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

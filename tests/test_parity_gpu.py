@@ -1,0 +1,324 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact for the fixed-point grid (integers) AND for the float
+grid and particle state (the kernels use the oracle's IEEE operation order with fused
+multiply-add disabled; the stated requirement is only 1e-5 relative for particle state)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import flow_amd
+from flow_amd import _lib
+from flow_amd.particles import dam_break, reference_scene
+from helpers import DEFAULT_UNIFORMS, assert_bits_equal, moving_particles
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALGOS = [pytest.param(_lib.ALGO_SCATTER, id="scatter"), pytest.param(_lib.ALGO_TILED, id="tiled")]
+
+
+def _handle(grid, rec, algo, uniforms=DEFAULT_UNIFORMS, rebin_interval=1, max_particles=None):
+    h = flow_amd.Handle(grid, max_particles or max(rec.shape[0], 1), algorithm=algo,
+                        rebin_interval=rebin_interval)
+    h.upload_particles(rec)
+    h.set_uniforms(**uniforms)
+    return h
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_each_kernel_matches_oracle(oracle_binding, algo):
+    grid, n = (32, 24, 16), 6000
+    rec = moving_particles(n, grid, seed=21)
+    h = _handle(grid, rec, algo)
+    orc = oracle_binding.Oracle(grid)
+    u = oracle_binding.make_uniforms(grid, n, **DEFAULT_UNIFORMS)
+    want = rec.copy()
+
+    h.run_kernel(_lib.KERNEL_CLEAR_GRID)
+    orc.clear_grid()
+    assert not h.download_grid_i32().any() and not h.download_grid_f32().any()
+
+    h.run_kernel(_lib.KERNEL_P2G1)
+    orc.p2g1(want, u)
+    assert np.array_equal(h.download_grid_i32(), orc.cell), "grid after p2g1"
+
+    h.run_kernel(_lib.KERNEL_P2G2)
+    orc.p2g2(want, u)
+    assert np.array_equal(h.download_grid_i32(), orc.cell), "grid after p2g2"
+    assert_bits_equal(h.download_field(_lib.FIELD_DENSITY)[:, 0], want[:, 3], "density after p2g2")
+
+    h.run_kernel(_lib.KERNEL_UPDATE_GRID)
+    orc.update_grid(u)
+    assert_bits_equal(h.download_grid_f32(), orc.cellf, "float grid after updateGrid")
+
+    h.run_kernel(_lib.KERNEL_G2P)
+    orc.g2p(want, u)
+    assert_bits_equal(h.download_particles(), want, "particles after g2p")
+    h.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_golden_small_case(algo):
+    """Committed vectors (tests/golden/make_golden.py), including the mouse-force branch."""
+    meta = json.load(open(os.path.join(GOLDEN, "small_16cube_512.json")))
+    g = np.load(os.path.join(GOLDEN, "small_16cube_512.npz"))
+    grid = tuple(meta["grid"])
+    h = _handle(grid, g["particles_in"], algo, uniforms=meta["uniforms"])
+    h.run_kernel(_lib.KERNEL_CLEAR_GRID)
+    h.run_kernel(_lib.KERNEL_P2G1)
+    assert np.array_equal(h.download_grid_i32(), g["cell_after_p2g1"])
+    h.run_kernel(_lib.KERNEL_P2G2)
+    assert np.array_equal(h.download_grid_i32(), g["cell_after_p2g2"])
+    h.run_kernel(_lib.KERNEL_UPDATE_GRID)
+    assert_bits_equal(h.download_grid_f32(), g["cellf_after_update"], "cellf")
+    h.run_kernel(_lib.KERNEL_G2P)
+    assert_bits_equal(h.download_particles(), g["particles_step1"], "particles step 1")
+    h.step(meta["steps_after_first"], meta["dtime"])
+    assert_bits_equal(h.download_particles(), g["particles_step4"], "particles step 4")
+    assert np.array_equal(h.download_grid_i32(), g["cell_step4"])
+    h.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_default_scene_digest(algo):
+    """The reference's default scene (81,920 particles, 128x64x64), one step."""
+    d = json.load(open(os.path.join(GOLDEN, "default_scene_step1.json")))
+    grid, n = tuple(d["grid"]), d["particles"]
+    h = _handle(grid, reference_scene(n, grid, seed=d["seed"]), algo, uniforms=d["uniforms"])
+    h.step(1)
+    cell = h.download_grid_i32()
+    assert hashlib.sha256(cell.tobytes()).hexdigest() == d["sha256_cell_i32"]
+    assert hashlib.sha256(h.download_grid_f32().tobytes()).hexdigest() == d["sha256_cellf"]
+    assert hashlib.sha256(h.download_particles().tobytes()).hexdigest() == d["sha256_particles"]
+    assert int(cell[:, 3].astype(np.int64).sum()) == d["grid_mass_sum_i64"]
+    h.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("rebin_interval", [1, 3, 50])
+def test_many_steps_match_oracle(oracle_binding, algo, rebin_interval):
+    """20 steps: stale bins (rebin_interval > 1) must not change a single bit."""
+    if algo == _lib.ALGO_SCATTER and rebin_interval != 1:
+        pytest.skip("re-binning is a tiled-path parameter")
+    grid, n = (32, 16, 16), 5000
+    rec = moving_particles(n, grid, seed=22, vel=1.5)       # fast particles cross tiles quickly
+    h = _handle(grid, rec, algo, rebin_interval=rebin_interval)
+    orc = oracle_binding.Oracle(grid)
+    want = rec.copy()
+    h.step(20, 1 / 60)
+    orc.run(want, oracle_binding.make_uniforms(grid, n, **DEFAULT_UNIFORMS), 20, 1 / 60)
+    assert np.array_equal(h.download_grid_i32(), orc.cell)
+    assert_bits_equal(h.download_grid_f32(), orc.cellf, "float grid")
+    assert_bits_equal(h.download_particles(), want, "particles after 20 steps")
+    h.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 257, 4097])
+def test_empty_and_ragged_particle_counts(oracle_binding, algo, n):
+    grid = (16, 16, 16)
+    rec = moving_particles(n, grid, seed=30 + n) if n else np.zeros((0, 28), np.float32)
+    h = _handle(grid, rec, algo)
+    h.step(2, 0.5)
+    orc = oracle_binding.Oracle(grid)
+    want = rec.copy()
+    if n:
+        orc.run(want, oracle_binding.make_uniforms(grid, n, **DEFAULT_UNIFORMS), 2, 0.5)
+    assert np.array_equal(h.download_grid_i32(), orc.cell)
+    assert_bits_equal(h.download_grid_f32(), orc.cellf, "float grid")
+    if n:
+        assert_bits_equal(h.download_particles(), want, "particles")
+    h.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_particles_on_the_walls_and_non_multiple_of_tile_grid(oracle_binding, algo):
+    """Positions on the clamp planes [2, g-2] and a grid that is not a multiple of the tile."""
+    grid, n = (21, 13, 10), 3000
+    rng = np.random.default_rng(5)
+    rec = moving_particles(n, grid, seed=23, vel=2.0)
+    lo, hi = 2.0, np.array(grid, np.float32) - 2.0
+    rec[:, 0:3] = lo + rng.random((n, 3), dtype=np.float32) * (hi - lo)
+    rec[: n // 6, 0] = 2.0
+    rec[n // 6: n // 3, 0] = hi[0]
+    rec[n // 3: n // 2, 1] = hi[1]
+    rec[n // 2: 2 * n // 3, 2] = 2.0
+    h = _handle(grid, rec, algo, rebin_interval=2)
+    orc = oracle_binding.Oracle(grid)
+    want = rec.copy()
+    h.step(6, 1 / 60)
+    orc.run(want, oracle_binding.make_uniforms(grid, n, **DEFAULT_UNIFORMS), 6, 1 / 60)
+    assert np.array_equal(h.download_grid_i32(), orc.cell)
+    assert_bits_equal(h.download_particles(), want, "particles")
+    h.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_dense_cluster_wraps_like_the_reference(oracle_binding, algo):
+    """Thousands of particles in a few cells: the i32 grid overflows and must wrap modulo 2^32
+    exactly as atomicAdd<i32> does (SIM:43, 326-329)."""
+    grid, n = (16, 16, 16), 9000
+    rng = np.random.default_rng(8)
+    rec = moving_particles(n, grid, seed=24)
+    rec[:, 0:3] = (7.0 + rng.random((n, 3), dtype=np.float32) * 2.0).astype(np.float32)
+    h = _handle(grid, rec, algo)
+    orc = oracle_binding.Oracle(grid)
+    want = rec.copy()
+    h.step(1)
+    orc.step(want, oracle_binding.make_uniforms(grid, n, **DEFAULT_UNIFORMS))
+    assert int(np.abs(orc.cell[:, 3].astype(np.int64)).max()) > 0
+    assert n * 1e7 > 2 ** 31 * 8             # far more mass than 8 cells can hold unwrapped
+    assert np.array_equal(h.download_grid_i32(), orc.cell)
+    assert_bits_equal(h.download_particles(), want, "particles")
+    h.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_mouse_force_and_zero_noise(oracle_binding, algo):
+    grid, n = (32, 16, 16), 4000
+    uni = dict(DEFAULT_UNIFORMS, noise=0.0, cursor_interaction=1, mouse_ray_direction=(0.0, 0.0, 1.0),
+               mouse_ray_origin=(16.0, 8.0, 0.0), mouse_force=(0.8, -0.3, 0.2))
+    rec = moving_particles(n, grid, seed=25)
+    h = _handle(grid, rec, algo, uniforms=uni)
+    orc = oracle_binding.Oracle(grid)
+    want = rec.copy()
+    h.step(3, 0.0)
+    orc.run(want, oracle_binding.make_uniforms(grid, n, **uni), 3, 0.0)
+    assert_bits_equal(h.download_particles(), want, "particles")
+    h.close()
+
+
+def test_scatter_and_tiled_agree_at_full_size():
+    """Benchmark configuration 2 (2^20 particles, 128^3): too big for the oracle in a test, so
+    check what is size-independent: both algorithms produce identical bits, and the fixed-point
+    grid mass equals the sum over particles of their 27 truncated weights."""
+    grid, n = (128, 128, 128), 1 << 20
+    rec = reference_scene(n, grid, seed=0xF10E5EED + 2)
+    uni = dict(DEFAULT_UNIFORMS, noise=0.0, rest_density=n / (0.268 * 128 ** 3))
+    outs = []
+    for algo in (_lib.ALGO_SCATTER, _lib.ALGO_TILED):
+        h = _handle(grid, rec, algo, uniforms=uni, rebin_interval=4)
+        h.step(6, 0.0)
+        outs.append((h.download_grid_i32(), h.download_particles()))
+        h.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert_bits_equal(outs[0][1], outs[1][1], "particles scatter vs tiled")
+    # mass bookkeeping on the state the grid was built from (positions before the last g2p are
+    # gone, so rebuild the grid from the current particles with p2g1 alone)
+    h = _handle(grid, outs[1][1], _lib.ALGO_TILED, uniforms=uni)
+    h.run_kernel(_lib.KERNEL_CLEAR_GRID)
+    h.run_kernel(_lib.KERNEL_P2G1)
+    cell = h.download_grid_i32()
+    h.close()
+    pos = outs[1][1][:, 0:3]
+    d = (pos - np.floor(pos)) - np.float32(0.5)
+    w = [(np.float32(0.5) * (np.float32(0.5) - d)) * (np.float32(0.5) - d), np.float32(0.75) - d * d,
+         (np.float32(0.5) * (np.float32(0.5) + d)) * (np.float32(0.5) + d)]
+    want = 0
+    for gx in range(3):
+        for gy in range(3):
+            for gz in range(3):
+                wt = (w[gx][:, 0] * w[gy][:, 1]) * w[gz][:, 2]
+                want += int(np.trunc((wt * np.float32(1e7)).astype(np.float64)).sum())
+    assert int(cell[:, 3].astype(np.int64).sum()) == want
+
+
+def test_permutation_invariance_on_gpu():
+    grid, n = (64, 32, 32), 100000
+    rec = moving_particles(n, grid, seed=26)
+    perm = np.random.default_rng(3).permutation(n)
+    a = _handle(grid, rec, _lib.ALGO_TILED)
+    b = _handle(grid, np.ascontiguousarray(rec[perm]), _lib.ALGO_TILED)
+    a.step(2)
+    b.step(2)
+    assert np.array_equal(a.download_grid_i32(), b.download_grid_i32())
+    assert_bits_equal(a.download_particles()[perm], b.download_particles(), "permuted particles")
+    a.close()
+    b.close()
+
+
+def test_dam_break_cluster_matches_oracle(oracle_binding):
+    grid, n = (32, 16, 16), 30000          # ~27 particles per cell in the column
+    rec = dam_break(n, grid, seed=5)
+    uni = dict(DEFAULT_UNIFORMS, noise=0.0, rest_density=20.0)
+    h = _handle(grid, rec, _lib.ALGO_TILED, uniforms=uni, rebin_interval=2)
+    orc = oracle_binding.Oracle(grid, threads=4)
+    want = rec.copy()
+    h.step(4, 0.0)
+    orc.run(want, oracle_binding.make_uniforms(grid, n, **uni), 4, 0.0)
+    assert np.array_equal(h.download_grid_i32(), orc.cell)
+    assert_bits_equal(h.download_particles(), want, "dam-break particles")
+    h.close()
+
+
+def test_set_num_particles_and_fields(oracle_binding):
+    """conf.particles < conf.maxParticles: only the first ids are simulated (SIM:2513-2522);
+    the rest keep their uploaded state."""
+    grid, total, live = (32, 16, 16), 3000, 1200
+    rec = moving_particles(total, grid, seed=27)
+    h = _handle(grid, rec, _lib.ALGO_TILED)
+    h.set_num_particles(live)
+    h.step(3, 0.1)
+    got = h.download_particles()
+    orc = oracle_binding.Oracle(grid)
+    want = rec.copy()
+    orc.run(want, oracle_binding.make_uniforms(grid, live, **DEFAULT_UNIFORMS), 3, 0.1)
+    assert_bits_equal(got, want, "all records, live and parked")
+    assert_bits_equal(h.download_field(_lib.FIELD_POSITION), want[:live, 0:3], "positions")
+    assert_bits_equal(h.download_field(_lib.FIELD_VELOCITY), want[:live, 4:7], "velocities")
+    assert_bits_equal(h.download_field(_lib.FIELD_COLOR), want[:live, 24:27], "colors")
+    h.set_num_particles(total)             # growing the live set resumes the parked records
+    h.step(1)
+    orc2 = oracle_binding.Oracle(grid)
+    orc2.step(want, oracle_binding.make_uniforms(grid, total, **DEFAULT_UNIFORMS))
+    assert_bits_equal(h.download_particles(), want, "after growing the live set")
+    h.close()
+
+
+def test_errors_are_loud():
+    grid = (16, 16, 16)
+    h = flow_amd.Handle(grid, 10)
+    bad = np.zeros((1, 28), np.float32)
+    bad[0, 0:3] = (0.5, 8, 8)                      # stencil would leave the grid
+    with pytest.raises(_lib.FlowMpmError) as e:
+        h.upload_particles(bad)
+    assert e.value.code == _lib.ERR_INVALID
+    with pytest.raises(_lib.FlowMpmError) as e:
+        h.upload_particles(np.zeros((11, 28), np.float32) + 8)
+    assert e.value.code == _lib.ERR_CAPACITY
+    with pytest.raises(_lib.FlowMpmError) as e:
+        h.set_uniforms(grid_mode=1)
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    with pytest.raises(_lib.FlowMpmError) as e:
+        h.run_kernel(17)
+    assert e.value.code == _lib.ERR_INVALID
+    h.close()
+    with pytest.raises(_lib.FlowMpmError):
+        flow_amd.Handle((4, 4, 4), 10)
+
+
+def test_simulator_class_follows_the_reference_frame_loop(oracle_binding):
+    """MlsMpmSimulator.update() drives the library as the reference's update() drives three.js:
+    default scene, conf defaults, 3 frames."""
+    from flow_amd.conf import Conf
+    sim = flow_amd.MlsMpmSimulator(None, conf=Conf(), rebin_interval=2)
+    sim.conf.maxParticles, sim.conf.particles = 16384, 8192
+    sim.conf.updateParams()
+    sim.init()
+    rec = sim.particleBuffer.records().copy()
+    for frame in range(3):
+        sim.update(1 / 30, 0.5 * frame)            # interval is clamped to 1/60 -> dt = 0.1
+    got = sim.readAoS()
+    grid, live = (128, 64, 64), 8192
+    orc = oracle_binding.Oracle(grid, threads=4)
+    want = rec.copy()
+    for frame in range(3):
+        u = oracle_binding.make_uniforms(grid, live, dt=(1 / 60) * 6, stiffness=3.0, rest_density=0.25,
+                                         dynamic_viscosity=0.1, noise=1.0, time=0.5 * frame)
+        orc.step(want, u)
+    assert_bits_equal(got, want, "simulator records after 3 frames")
+    assert_bits_equal(sim.getPositions(), want[:live, 0:3], "getPositions")
+    assert_bits_equal(sim.getDensities()[:, 0], want[:live, 3], "getDensities")
