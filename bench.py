@@ -1,0 +1,230 @@
+"""Benchmark of the MLS-MPM step (particle-substeps/sec) on N MI355X GPUs of one node.
+
+A "step" is one reference update(): clearGrid -> p2g1 -> p2g2 -> updateGrid -> g2p
+(src/mls-mpm/mlsMpmSimulator.js:2538-2539) over synthetic particles already resident in HBM.
+
+N = 1 : benchmark configuration "16M particles, 256^3 grid, single MI355X".
+N > 1 : weak scaling, one rank per GPU: rank r owns an x-slab of a (64*N) x 512 x 512
+        domain holding N * 2^24 particles (N = 8 is "128M particles, 512^3 grid"); halo
+        planes and migrating particles travel over RCCL through torch.distributed.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec; measured copy ceiling is ~6290 GB/s
+# Algorithmic bytes (fp32 SoA, every array touched once per kernel that needs it, grid tiles
+# perfectly reused on chip): per particle-step and per cell-step.
+BYTES = {
+    "clearGrid": (0, 32), "p2g1": (60, 16), "p2g2": (56, 16), "updateGrid": (0, 32), "g2p": (96, 16),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--algorithm", choices=("tiled", "scatter"), default="tiled")
+    ap.add_argument("--rebin-interval", type=int, default=1)
+    ap.add_argument("--particles-log2", type=int, default=24, help="particles per GPU = 2^k")
+    ap.add_argument("--grid", type=str, default="", help="override the N=1 grid, e.g. 128,128,128")
+    ap.add_argument("--scene", choices=("ellipsoid", "dam_break"), default="ellipsoid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def scene_uniforms(n_particles, grid_cells, scene):
+    """Benchmark uniforms: rest density set so the mean density is about the rest density
+    (the ellipsoid fills 0.268 of the box), dt = 0.1, no noise, no mouse force."""
+    fill = 0.268 if scene == "ellipsoid" else 0.25
+    return dict(dt=0.1, stiffness=3.0, rest_density=n_particles / (fill * grid_cells),
+                dynamic_viscosity=0.1, noise=0.0, time=0.0)
+
+
+def make_particles(scene, count, grid, seed, first_id=0):
+    from flow_amd.particles import dam_break, reference_scene
+    chunk = 1 << 21
+    out = np.empty((count, 28), dtype=np.float32)
+    fn = reference_scene if scene == "ellipsoid" else dam_break
+    for lo in range(0, count, chunk):
+        hi = min(count, lo + chunk)
+        out[lo:hi] = fn(hi - lo, grid, seed=seed, first_id=first_id + lo)
+    return out
+
+
+def cpu_baseline(rec, n, grid, uniforms, steps):
+    """The CPU oracle (same algorithm as the reference: one iteration per particle, relaxed
+    i32 atomic adds on 16-byte cell records, 112-byte AoS particles), OpenMP over the host
+    cores, on a bounded sample: the same particles and grid, `steps` steps."""
+    from oracle import binding
+    binding.build()
+    cores = max(1, min(16, os.cpu_count() or 1))
+    orc = binding.Oracle(grid, threads=cores)
+    u = binding.make_uniforms(grid, n, **uniforms)
+    orc.run(rec, u, 1, 0.0)                       # touch pages, warm caches
+    t0 = time.perf_counter()
+    orc.run(rec, u, steps, 0.0)
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "particle-substeps/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the same workload (%d particles, grid %dx%dx%d), oracle in OpenMP mode"
+                      % (steps, n, grid[0], grid[1], grid[2])}
+
+
+def roofline_of(timings, n, cells):
+    """Roofline entry of the kernel with the largest share of the step."""
+    best, out = None, {}
+    for name, (bp, bc) in BYTES.items():
+        t = timings[name]
+        if t["launches"] == 0:
+            continue
+        avg_ms = t["ms"] / t["launches"]
+        gbs = (bp * n + bc * cells) / (avg_ms * 1e-3) / 1e9
+        out[name] = {"avg_ms": round(avg_ms, 4), "algorithmic_GBs": round(gbs, 1),
+                     "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        if best is None or avg_ms > best[1]:
+            best = (name, avg_ms, gbs)
+    name, avg_ms, gbs = best
+    roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4)}
+    return roof, out
+
+
+def run_single(args):
+    import flow_amd
+    from flow_amd import _lib
+    n = 1 << args.particles_log2
+    grid = tuple(int(x) for x in args.grid.split(",")) if args.grid else (256, 256, 256)
+    cells = grid[0] * grid[1] * grid[2]
+    seed = 0xF10E5EED + 3
+    uniforms = scene_uniforms(n, cells, args.scene)
+    algo = _lib.ALGO_TILED if args.algorithm == "tiled" else _lib.ALGO_SCATTER
+    h = flow_amd.Handle(grid, n, device=0, algorithm=algo, rebin_interval=args.rebin_interval)
+    rec = make_particles(args.scene, n, grid, seed)
+    h.upload_particles(rec)
+    h.set_uniforms(**uniforms)
+    h.step(args.warmup, 0.0)
+    h.synchronize()
+    h.set_profiling(True)
+    h.reset_timings()
+    t0 = time.perf_counter()
+    h.step(args.steps, 0.0)
+    h.synchronize()
+    elapsed = time.perf_counter() - t0
+    timings = h.timings()
+    h.close()
+    roof, per_kernel = roofline_of(timings, n, cells)
+    rebin = timings["rebin"]
+    step_bytes = 212 * n + 112 * cells
+    line = {
+        "metric": "particle-substeps/sec", "value": n * args.steps / elapsed, "unit": "particle-substeps/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+i32-fixed-point",
+        "data": "synthetic",
+        "config": {"workload": "16M particles, 256^3 grid, single MI355X" if (args.particles_log2 == 24 and not args.grid)
+                   else "%d particles, grid %dx%dx%d, single MI355X" % (n, grid[0], grid[1], grid[2]),
+                   "scene": args.scene, "particles": n, "grid": list(grid), "algorithm": args.algorithm,
+                   "rebin_interval": args.rebin_interval, "dt": 0.1, "noise": 0.0, "cursor_interaction": 0},
+        "roofline": roof,
+        "step_roofline": {"algorithmic_bytes_per_step": step_bytes,
+                          "achieved_GBs": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
+                          "frac_of_8TBs": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+        "kernels": per_kernel,
+        "rebin": {"launches": rebin["launches"],
+                  "avg_ms": round(rebin["ms"] / rebin["launches"], 4) if rebin["launches"] else None},
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(rec, n, grid, uniforms, args.cpu_steps)
+    return line
+
+
+def run_distributed(args):
+    import torch
+    import torch.distributed as dist
+    from flow_amd import _lib
+    from flow_amd.slab import SlabSimulation, balanced_plane_starts
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_per = 1 << args.particles_log2
+    n_total = n_per * world
+    grid = (64 * world, 512, 512)
+    cells = grid[0] * grid[1] * grid[2]
+    seed = 0xF10E5EED + 4
+    uniforms = scene_uniforms(n_total, cells, args.scene)
+    algo = _lib.ALGO_TILED if args.algorithm == "tiled" else _lib.ALGO_SCATTER
+
+    # Every rank generates the id range [rank*n_per, (rank+1)*n_per) of the global scene; the
+    # slab boundaries are chosen so that every slab starts with about the same particle count.
+    mine = make_particles(args.scene, n_per, grid, seed, first_id=rank * n_per)
+    ids = np.arange(rank * n_per, (rank + 1) * n_per, dtype=np.int32)
+    starts = balanced_plane_starts(mine[:, 0], grid[0], world, dist)
+    sim = SlabSimulation(grid, starts, rank, world, max_particles=int(n_per * 2.5), device=local_rank,
+                         algorithm=algo, rebin_interval=args.rebin_interval, dist=dist,
+                         torch_device=torch.device("cuda", local_rank))
+    sim.scatter_initial_particles(mine, ids)
+    sim.set_uniforms(**uniforms)
+    for _ in range(args.warmup):
+        sim.step()
+    sim.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+    sim.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    resident = torch.tensor([sim.resident()], dtype=torch.int64, device="cuda")
+    gathered = [torch.zeros_like(resident) for _ in range(world)]
+    dist.all_gather(gathered, resident)
+    line = None
+    if rank == 0:
+        per_rank = [int(g.item()) for g in gathered]
+        line = {
+            "metric": "particle-substeps/sec", "value": n_total * args.steps / elapsed,
+            "unit": "particle-substeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32+i32-fixed-point", "data": "synthetic",
+            "config": {"workload": "%dM particles, %dx512x512 grid, %d x-slabs over %d MI355X (2^24 particles per GPU)"
+                                   % (n_total >> 20, grid[0], world, world),
+                       "scene": args.scene, "particles": n_total, "grid": list(grid), "algorithm": args.algorithm,
+                       "rebin_interval": args.rebin_interval, "parallelism": "slab%d" % world,
+                       "plane_starts": [int(s) for s in starts], "resident_per_rank_end": per_rank},
+            "roofline": None, "cpu_baseline": None,
+        }
+    dist.destroy_process_group()
+    return line
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        if world != args.gpus:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)"
+                             % (args.gpus, world))
+        line = run_distributed(args)
+    else:
+        line = run_single(args)
+    if line is not None:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
