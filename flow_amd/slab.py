@@ -1,0 +1,298 @@
+"""x-slab decomposition of the MLS-MPM step over the GPUs of one node.
+
+The reference runs on one GPU; this module has no counterpart there.  The cell index is
+x-major (src/mls-mpm/mlsMpmSimulator.js:286-290), so a slab of x-planes is one contiguous
+block of both grids, and a particle with floor(x) = ix touches planes ix-1 .. ix+1
+(SIM:307, 315-319): every slab keeps one halo plane on each side.
+
+One process per GPU.  Per step and per neighbour (point-to-point send/recv over RCCL, i.e.
+one xGMI link per neighbour; no all-reduce on the data path):
+
+  clearGrid, p2g1
+  exchange A  both boundary planes (halo + first owned) go to the neighbour, which adds the
+              MASS component into its matching planes            -> mass complete for p2g2
+  p2g2
+  exchange B  same planes again, the neighbour adds the MOMENTUM components
+  updateGrid  on owned and halo planes alike (redundant on halos, saves a third exchange)
+  g2p
+  migrate     particles whose floor(x) left the slab are packed, counted (one small
+              all_gather of the count matrix) and sent straight to their owner
+
+The grid is fixed-point i32 and the merges are integer adds, so the result is bit-identical
+to the single-GPU grid for any number of slabs; tests assert exactly that.
+
+`SlabSimulation` only speaks to a *backend* object (kernels + plane access + migration
+pieces) and to `torch.distributed`, so the protocol itself is exercised on CPU with the
+gloo backend in the tests, and runs on GPUs with `GpuSlabBackend`.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+RECORD_WORDS = _lib.MIGRATE_WORDS
+
+
+def equal_plane_starts(grid_x, world):
+    return [round(r * grid_x / world) for r in range(world + 1)]
+
+
+def balanced_plane_starts(x_positions, grid_x, world, dist=None, device=None):
+    """Slab boundaries that give every rank about the same number of particles: the global
+    histogram of floor(x) is summed over ranks and cut at equal quantiles.  Every slab gets
+    at least 2 planes."""
+    hist = np.bincount(np.clip(np.floor(x_positions).astype(np.int64), 0, grid_x - 1), minlength=grid_x)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.from_numpy(hist.astype(np.int64))
+        if device is None and dist.get_backend() == "nccl":
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t)
+        hist = t.cpu().numpy()
+    cum = np.cumsum(hist)
+    total = int(cum[-1])
+    starts = [0]
+    for r in range(1, world):
+        cut = int(np.searchsorted(cum, total * r / world, side="left")) + 1
+        cut = max(cut, starts[-1] + 2)
+        cut = min(cut, grid_x - 2 * (world - r))
+        starts.append(cut)
+    starts.append(grid_x)
+    return starts
+
+
+class _Transport:
+    """Point-to-point exchange over torch.distributed.  RCCL moves device tensors directly;
+    gloo (CPU rehearsals) cannot send device tensors, so they are staged through the host."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.stage = dist.get_backend() == "gloo"
+
+    def exchange(self, sends, recvs):
+        """sends: list of (tensor, peer); recvs: list of (tensor, peer).  Blocks until the
+        received tensors are usable on the current stream."""
+        if not sends and not recvs:
+            return
+        dist = self.dist
+        ops, staged = [], []
+        for t, peer in sends:
+            buf = t.cpu() if (self.stage and t.is_cuda) else t
+            ops.append(dist.P2POp(dist.isend, buf, peer))
+        for t, peer in recvs:
+            if self.stage and t.is_cuda:
+                buf = torch.empty(t.shape, dtype=t.dtype)
+                staged.append((t, buf))
+            else:
+                buf = t
+            ops.append(dist.P2POp(dist.irecv, buf, peer))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for t, buf in staged:
+            t.copy_(buf)
+
+
+class GpuSlabBackend:
+    """The device-side pieces of one slab: a flowmpm handle enqueueing on torch's current
+    stream (so RCCL operations issued through torch order against the kernels) plus torch
+    tensors as send/receive staging."""
+
+    def __init__(self, grid, slab_x0, slab_nx, max_particles, device, algorithm, rebin_interval):
+        from .simulator import Handle
+        self.torch_device = torch.device("cuda", device)
+        torch.cuda.set_device(self.torch_device)
+        stream = torch.cuda.current_stream(self.torch_device).cuda_stream
+        self.handle = Handle(grid, max_particles, device=device, algorithm=algorithm,
+                             rebin_interval=rebin_interval, slab=(slab_x0, slab_nx), stream=stream)
+        self.plane_words = grid[1] * grid[2] * 4
+        self.max_particles = max_particles
+        self._leavers = torch.empty((max(max_particles // 4, 1024), RECORD_WORDS), dtype=torch.float32,
+                                    device=self.torch_device)
+
+    def set_uniforms(self, **kw):
+        self.handle.set_uniforms(**kw)
+
+    def run_kernel(self, kernel_id):
+        self.handle.run_kernel(kernel_id)
+
+    def upload(self, records, ids):
+        self.handle.upload_particles(records, ids)
+
+    def download(self):
+        return self.handle.download_particles()
+
+    def resident(self):
+        return self.handle.num_particles()[1]
+
+    def new_plane_buffer(self, planes):
+        return torch.empty((planes, self.plane_words), dtype=torch.int32, device=self.torch_device)
+
+    def plane_read(self, plane, out):
+        self.handle.plane_copy_out(plane, out.data_ptr())
+
+    def plane_add(self, plane, src, mask):
+        self.handle.plane_add_i32(plane, src.data_ptr(), mask)
+
+    def extract_leavers(self, plane_starts):
+        counts = self.handle.extract_leavers(plane_starts, self._leavers.data_ptr(), self._leavers.shape[0])
+        return counts, self._leavers[: int(counts.sum())]
+
+    def new_record_buffer(self, count):
+        return torch.empty((count, RECORD_WORDS), dtype=torch.float32, device=self.torch_device)
+
+    def insert_arrivals(self, records):
+        self.handle.insert_arrivals(records.data_ptr(), records.shape[0])
+
+    def synchronize(self):
+        self.handle.synchronize()
+
+    def close(self):
+        self.handle.close()
+
+
+class SlabSimulation:
+    def __init__(self, grid, plane_starts, rank, world, max_particles=0, device=0,
+                 algorithm=_lib.ALGO_TILED, rebin_interval=1, dist=None, torch_device=None, backend=None):
+        self.grid = tuple(int(g) for g in grid)
+        self.plane_starts = [int(s) for s in plane_starts]
+        assert len(self.plane_starts) == world + 1 and self.plane_starts[0] == 0
+        assert self.plane_starts[-1] == self.grid[0]
+        self.rank, self.world, self.dist = rank, world, dist
+        self.x0 = self.plane_starts[rank]
+        self.nx = self.plane_starts[rank + 1] - self.x0
+        self.backend = backend if backend is not None else GpuSlabBackend(
+            self.grid, self.x0, self.nx, max_particles, device, algorithm, rebin_interval)
+        self.transport = _Transport(dist) if (dist is not None and world > 1) else None
+        self.low = rank - 1 if rank > 0 else None
+        self.high = rank + 1 if rank < world - 1 else None
+        b = self.backend
+        self._send = {side: b.new_plane_buffer(2) for side in ("low", "high")}
+        self._recv = {side: b.new_plane_buffer(2) for side in ("low", "high")}
+
+    # ---- set-up ----
+    def set_uniforms(self, **kw):
+        self.backend.set_uniforms(**kw)
+
+    def scatter_initial_particles(self, records, ids):
+        """Every rank brings any subset of the global particles; each record is routed to the
+        rank that owns floor(x), then uploaded there with its global id."""
+        records = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, _lib.PARTICLE_STRIDE)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        starts = np.asarray(self.plane_starts)
+        dest = np.clip(np.searchsorted(starts, np.floor(records[:, 0]).astype(np.int64), side="right") - 1,
+                       0, self.world - 1)
+        if self.world == 1:
+            self.backend.upload(records, ids)
+            return
+        order = np.argsort(dest, kind="stable")
+        counts = np.bincount(dest, minlength=self.world).astype(np.int64)
+        packed = np.empty((records.shape[0], _lib.PARTICLE_STRIDE + 1), dtype=np.float32)
+        packed[:, :_lib.PARTICLE_STRIDE] = records[order]
+        packed[:, _lib.PARTICLE_STRIDE] = ids[order].view(np.float32)
+        mine, offs = [], np.concatenate([[0], np.cumsum(counts)])
+        dev = self._comm_device()
+        matrix = self._all_gather_counts(counts, dev)
+        send_t = torch.from_numpy(packed).to(dev)
+        sends, recvs, inbox = [], [], []
+        for peer in range(self.world):
+            if peer == self.rank:
+                mine.append(packed[offs[peer]:offs[peer + 1]])
+                continue
+            if counts[peer]:
+                sends.append((send_t[offs[peer]:offs[peer + 1]], peer))
+            k = int(matrix[peer, self.rank])
+            if k:
+                buf = torch.empty((k, _lib.PARTICLE_STRIDE + 1), dtype=torch.float32, device=dev)
+                inbox.append(buf)
+                recvs.append((buf, peer))
+        self.transport.exchange(sends, recvs)
+        mine += [b.cpu().numpy() for b in inbox]
+        allrec = np.concatenate(mine, axis=0) if mine else np.zeros((0, _lib.PARTICLE_STRIDE + 1), np.float32)
+        self.backend.upload(np.ascontiguousarray(allrec[:, :_lib.PARTICLE_STRIDE]),
+                            np.ascontiguousarray(allrec[:, _lib.PARTICLE_STRIDE]).view(np.int32))
+
+    def _comm_device(self):
+        if self.dist is not None and self.dist.get_backend() == "nccl":
+            return self.backend.torch_device
+        return torch.device("cpu")
+
+    def _all_gather_counts(self, counts, dev):
+        t = torch.from_numpy(np.asarray(counts, dtype=np.int64)).to(dev)
+        out = torch.empty(self.world * self.world, dtype=torch.int64, device=dev)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy().reshape(self.world, self.world)
+
+    # ---- the step ----
+    def _exchange_planes(self, mask):
+        if self.transport is None:
+            return
+        b = self.backend
+        sends, recvs = [], []
+        if self.low is not None:
+            b.plane_read(_lib.PLANE_LOW_HALO, self._send["low"][0])
+            b.plane_read(_lib.PLANE_LOW_OWNED, self._send["low"][1])
+            sends.append((self._send["low"], self.low))
+            recvs.append((self._recv["low"], self.low))
+        if self.high is not None:
+            b.plane_read(_lib.PLANE_HIGH_OWNED, self._send["high"][0])
+            b.plane_read(_lib.PLANE_HIGH_HALO, self._send["high"][1])
+            sends.append((self._send["high"], self.high))
+            recvs.append((self._recv["high"], self.high))
+        self.transport.exchange(sends, recvs)
+        # The low neighbour sent (its HIGH_OWNED, its HIGH_HALO) = (my LOW_HALO, my LOW_OWNED).
+        if self.low is not None:
+            b.plane_add(_lib.PLANE_LOW_HALO, self._recv["low"][0], mask)
+            b.plane_add(_lib.PLANE_LOW_OWNED, self._recv["low"][1], mask)
+        # The high neighbour sent (its LOW_HALO, its LOW_OWNED) = (my HIGH_OWNED, my HIGH_HALO).
+        if self.high is not None:
+            b.plane_add(_lib.PLANE_HIGH_OWNED, self._recv["high"][0], mask)
+            b.plane_add(_lib.PLANE_HIGH_HALO, self._recv["high"][1], mask)
+
+    def _migrate(self):
+        if self.transport is None:
+            return
+        b = self.backend
+        counts, packed = b.extract_leavers(self.plane_starts)
+        matrix = self._all_gather_counts(counts, self._comm_device())
+        if not matrix.any():
+            return
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        sends, recvs, inbox = [], [], []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            if counts[peer]:
+                sends.append((packed[int(offs[peer]):int(offs[peer + 1])], peer))
+            k = int(matrix[peer, self.rank])
+            if k:
+                buf = b.new_record_buffer(k)
+                inbox.append(buf)
+                recvs.append((buf, peer))
+        self.transport.exchange(sends, recvs)
+        for buf in inbox:
+            b.insert_arrivals(buf)
+
+    def step(self):
+        b = self.backend
+        b.run_kernel(_lib.KERNEL_CLEAR_GRID)
+        b.run_kernel(_lib.KERNEL_P2G1)
+        self._exchange_planes(_lib.COMP_MASS)
+        b.run_kernel(_lib.KERNEL_P2G2)
+        self._exchange_planes(_lib.COMP_MOMENTUM)
+        b.run_kernel(_lib.KERNEL_UPDATE_GRID)
+        b.run_kernel(_lib.KERNEL_G2P)
+        self._migrate()
+
+    def resident(self):
+        return self.backend.resident()
+
+    def synchronize(self):
+        self.backend.synchronize()
+
+    def download(self):
+        """(records, global ids) of the particles resident on this rank."""
+        return self.backend.download()
+
+    def close(self):
+        self.backend.close()

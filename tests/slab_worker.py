@@ -1,0 +1,188 @@
+"""One rank of a slab-decomposed run, launched by tests through torch.distributed.run.
+
+--backend oracle : the protocol of flow_amd.slab.SlabSimulation over gloo with the CPU oracle
+                   standing in for the HIP library (test infrastructure; runs without a GPU)
+--backend gpu    : the real library; every rank uses cuda:0 and the transport is gloo with host
+                   staging (a one-GPU rehearsal of the multi-GPU path)
+Each rank writes its resident particles and owned grid planes to --out/rank<r>.npz.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from flow_amd import _lib  # noqa: E402
+from flow_amd.slab import SlabSimulation, balanced_plane_starts, equal_plane_starts  # noqa: E402
+from helpers import DEFAULT_UNIFORMS, moving_particles  # noqa: E402
+
+
+class OracleSlabBackend:
+    """Backend interface of SlabSimulation implemented with the CPU oracle on a full-size grid
+    of which only this slab's planes (and halos) are ever non-zero."""
+
+    def __init__(self, grid, x0, nx):
+        from oracle import binding
+        self.binding = binding
+        self.grid, self.x0, self.nx = grid, x0, nx
+        self.orc = binding.Oracle(grid)
+        self.rec = np.zeros((0, 28), np.float32)
+        self.ids = np.zeros(0, np.int32)
+        self.uniform_kw = {}
+        self.plane_words = grid[1] * grid[2] * 4
+        self.torch_device = torch.device("cpu")
+
+    def _u(self):
+        return self.binding.make_uniforms(self.grid, self.rec.shape[0], **self.uniform_kw)
+
+    def set_uniforms(self, **kw):
+        self.uniform_kw = kw
+
+    def run_kernel(self, k):
+        if k == _lib.KERNEL_CLEAR_GRID:
+            self.orc.clear_grid()
+        elif k == _lib.KERNEL_P2G1:
+            self.orc.p2g1(self.rec, self._u())
+        elif k == _lib.KERNEL_P2G2:
+            self.orc.p2g2(self.rec, self._u())
+        elif k == _lib.KERNEL_UPDATE_GRID:
+            self.orc.update_grid(self._u())
+        elif k == _lib.KERNEL_G2P:
+            self.orc.g2p(self.rec, self._u())
+
+    def upload(self, records, ids):
+        self.rec, self.ids = np.ascontiguousarray(records, np.float32).copy(), np.asarray(ids, np.int32).copy()
+
+    def download(self):
+        return self.rec.copy(), self.ids.copy()
+
+    def resident(self):
+        return self.rec.shape[0]
+
+    def _plane_x(self, plane):
+        return {_lib.PLANE_LOW_HALO: self.x0 - 1, _lib.PLANE_LOW_OWNED: self.x0,
+                _lib.PLANE_HIGH_OWNED: self.x0 + self.nx - 1, _lib.PLANE_HIGH_HALO: self.x0 + self.nx}[plane]
+
+    def _plane_view(self, plane):
+        per = self.grid[1] * self.grid[2]
+        x = self._plane_x(plane)
+        return self.orc.cell[x * per:(x + 1) * per]
+
+    def new_plane_buffer(self, planes):
+        return torch.zeros((planes, self.plane_words), dtype=torch.int32)
+
+    def plane_read(self, plane, out):
+        out.copy_(torch.from_numpy(self._plane_view(plane).reshape(-1).copy()))
+
+    def plane_add(self, plane, src, mask):
+        view = self._plane_view(plane).view(np.uint32)
+        add = src.numpy().reshape(-1, 4).view(np.uint32)
+        for c in range(4):
+            if mask & (1 << c):
+                view[:, c] += add[:, c]
+
+    def _pack(self, rows):
+        r = self.rec[rows]
+        out = np.zeros((len(rows), 24), np.float32)
+        out[:, 0:3], out[:, 3:6] = r[:, 0:3], r[:, 4:7]
+        for c in range(3):
+            out[:, 6 + 3 * c:9 + 3 * c] = r[:, 8 + 4 * c:11 + 4 * c]
+        out[:, 15], out[:, 16] = r[:, 3], r[:, 7]
+        out[:, 17:20], out[:, 20:23] = r[:, 20:23], r[:, 24:27]
+        out[:, 23] = self.ids[rows].view(np.float32)
+        return out
+
+    def extract_leavers(self, plane_starts):
+        ix = np.trunc(self.rec[:, 0]).astype(np.int64)
+        leaving = (ix < self.x0) | (ix >= self.x0 + self.nx)
+        world = len(plane_starts) - 1
+        dest = np.clip(np.searchsorted(np.asarray(plane_starts), ix, side="right") - 1, 0, world - 1)
+        rows = np.nonzero(leaving)[0]
+        rows = rows[np.argsort(dest[rows], kind="stable")]
+        counts = np.bincount(dest[rows], minlength=world).astype(np.int64)
+        packed = torch.from_numpy(self._pack(rows))
+        self.rec, self.ids = np.ascontiguousarray(self.rec[~leaving]), self.ids[~leaving]
+        return counts, packed
+
+    def new_record_buffer(self, count):
+        return torch.zeros((count, 24), dtype=torch.float32)
+
+    def insert_arrivals(self, records):
+        p = records.numpy()
+        r = np.zeros((p.shape[0], 28), np.float32)
+        r[:, 0:3], r[:, 4:7] = p[:, 0:3], p[:, 3:6]
+        for c in range(3):
+            r[:, 8 + 4 * c:11 + 4 * c] = p[:, 6 + 3 * c:9 + 3 * c]
+        r[:, 3], r[:, 7] = p[:, 15], p[:, 16]
+        r[:, 20:23], r[:, 24:27] = p[:, 17:20], p[:, 20:23]
+        self.rec = np.concatenate([self.rec, r])
+        self.ids = np.concatenate([self.ids, np.ascontiguousarray(p[:, 23]).view(np.int32)])
+
+    def owned_grid(self):
+        per = self.grid[1] * self.grid[2]
+        return (self.orc.cell[self.x0 * per:(self.x0 + self.nx) * per].copy(),
+                self.orc.cellf[self.x0 * per:(self.x0 + self.nx) * per].copy())
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", choices=("oracle", "gpu"), required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--grid", default="24,12,12")
+    ap.add_argument("--particles", type=int, default=2500)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--vel", type=float, default=3.0)
+    ap.add_argument("--balanced", action="store_true")
+    ap.add_argument("--algorithm", choices=("tiled", "scatter"), default="tiled")
+    args = ap.parse_args()
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    grid = tuple(int(g) for g in args.grid.split(","))
+    n = args.particles
+    rec = moving_particles(n, grid, seed=41, vel=args.vel)       # every rank builds the same scene
+    lo, hi = rank * n // world, (rank + 1) * n // world          # and contributes one id range
+    if args.balanced:
+        starts = balanced_plane_starts(rec[lo:hi, 0], grid[0], world, dist)
+    else:
+        starts = equal_plane_starts(grid[0], world)
+    x0, nx = starts[rank], starts[rank + 1] - starts[rank]
+    if args.backend == "oracle":
+        backend = OracleSlabBackend(grid, x0, nx)
+        sim = SlabSimulation(grid, starts, rank, world, dist=dist, backend=backend)
+    else:
+        algo = _lib.ALGO_TILED if args.algorithm == "tiled" else _lib.ALGO_SCATTER
+        sim = SlabSimulation(grid, starts, rank, world, max_particles=n, device=0, algorithm=algo,
+                             rebin_interval=2, dist=dist)
+    sim.scatter_initial_particles(rec[lo:hi], np.arange(lo, hi, dtype=np.int32))
+    for k in range(args.steps):
+        sim.set_uniforms(**dict(DEFAULT_UNIFORMS, time=0.25 * k))
+        sim.step()
+    sim.synchronize()
+    out_rec, out_ids = sim.download()
+    if args.backend == "oracle":
+        cell, cellf = sim.backend.owned_grid()
+    else:
+        per = grid[1] * grid[2]
+        cell = sim.backend.handle.download_grid_i32()[per:(nx + 1) * per]
+        cellf = sim.backend.handle.download_grid_f32()[per:(nx + 1) * per]
+    np.savez(os.path.join(args.out, "rank%d.npz" % rank), rec=out_rec, ids=out_ids, cell=cell, cellf=cellf,
+             starts=np.asarray(starts))
+    sim.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

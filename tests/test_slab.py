@@ -1,0 +1,177 @@
+"""The slab-decomposed path.  CPU: the exchange protocol over gloo with the oracle standing in
+for the library, world sizes 2 and 3, against the single-domain oracle.  GPU: the device-side
+pieces (plane add, leaver extraction, arrival insertion) in one process and a 2-rank rehearsal
+on one GPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import DEFAULT_UNIFORMS, assert_bits_equal, moving_particles
+from flow_amd import _lib
+from flow_amd.slab import balanced_plane_starts, equal_plane_starts
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(world, out, *extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--out", str(out)] + list(extra)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def _reference_run(oracle_binding, grid, n, steps, vel):
+    rec = moving_particles(n, grid, seed=41, vel=vel)
+    orc = oracle_binding.Oracle(grid)
+    for k in range(steps):
+        orc.step(rec, oracle_binding.make_uniforms(grid, n, **dict(DEFAULT_UNIFORMS, time=0.25 * k)))
+    return rec, orc
+
+
+def _check_against_single_domain(out, world, rec, orc, grid):
+    per = grid[1] * grid[2]
+    seen = np.zeros(rec.shape[0], bool)
+    moved = 0
+    for r in range(world):
+        d = np.load(os.path.join(out, "rank%d.npz" % r))
+        starts = d["starts"]
+        x0, x1 = int(starts[r]), int(starts[r + 1])
+        assert not seen[d["ids"]].any(), "a particle is resident on two ranks"
+        seen[d["ids"]] = True
+        assert_bits_equal(d["rec"], rec[d["ids"]], "particles on rank %d" % r)
+        ix = np.floor(d["rec"][:, 0]).astype(int)
+        assert ((ix >= x0) & (ix < x1)).all(), "rank %d holds a particle outside its slab" % r
+        assert np.array_equal(d["cell"], orc.cell[x0 * per:x1 * per]), "fixed-point grid of rank %d" % r
+        assert_bits_equal(d["cellf"], orc.cellf[x0 * per:x1 * per], "float grid of rank %d" % r)
+        n = rec.shape[0]
+        first_owner = np.arange(n)[d["ids"]] * world // n
+        moved += int((first_owner != r).sum())
+    assert seen.all(), "particles were lost"
+    return moved
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_protocol_on_cpu_matches_single_domain(oracle_binding, tmp_path, world):
+    grid, n, steps, vel = (24, 12, 12), 2500, 12, 3.0
+    _launch(world, tmp_path, "--backend", "oracle", "--grid", "24,12,12", "--particles", str(n),
+            "--steps", str(steps), "--vel", str(vel))
+    rec, orc = _reference_run(oracle_binding, grid, n, steps, vel)
+    moved = _check_against_single_domain(tmp_path, world, rec, orc, grid)
+    assert moved > 0, "the case must exercise migration"
+
+
+def test_slab_protocol_balanced_boundaries(oracle_binding, tmp_path):
+    grid, n, steps, vel = (32, 10, 10), 2000, 6, 2.0
+    _launch(2, tmp_path, "--backend", "oracle", "--grid", "32,10,10", "--particles", str(n),
+            "--steps", str(steps), "--vel", str(vel), "--balanced")
+    rec, orc = _reference_run(oracle_binding, grid, n, steps, vel)
+    _check_against_single_domain(tmp_path, 2, rec, orc, grid)
+
+
+def test_plane_starts_helpers():
+    assert equal_plane_starts(512, 8) == [0, 64, 128, 192, 256, 320, 384, 448, 512]
+    x = np.concatenate([np.full(900, 10.5), np.full(100, 50.5)])
+    s = balanced_plane_starts(x, 64, 4)
+    assert s[0] == 0 and s[-1] == 64 and all(b - a >= 2 for a, b in zip(s, s[1:]))
+    x = np.random.default_rng(0).uniform(2, 62, 100000)
+    s = balanced_plane_starts(x, 64, 4)
+    counts = np.histogram(np.floor(x), bins=s)[0]
+    assert counts.max() / counts.mean() < 1.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", [_lib.ALGO_SCATTER, _lib.ALGO_TILED])
+def test_two_slabs_in_one_process_match_single_domain(oracle_binding, algo):
+    """Drives two slab handles on one GPU with a local 'transport' (device copies), which
+    checks plane add, leaver extraction and arrival insertion against the oracle."""
+    import torch
+    from flow_amd.slab import SlabSimulation
+
+    grid, n, steps = (24, 16, 12), 4000, 10
+    rec = moving_particles(n, grid, seed=41, vel=3.0)
+    starts = [0, 11, 24]
+
+    class LocalDist:
+        """Stands in for torch.distributed between two in-process 'ranks'."""
+        def __init__(self):
+            self.box = {}
+
+    sims = [SlabSimulation(grid, starts, r, 2, max_particles=n, device=0, algorithm=algo, rebin_interval=2)
+            for r in range(2)]
+    dest = (np.floor(rec[:, 0]) >= starts[1]).astype(int)
+    for r, s in enumerate(sims):
+        rows = np.nonzero(dest == r)[0]
+        s.backend.upload(rec[rows], rows.astype(np.int32))
+
+    def exchange(mask):
+        a, b = sims[0].backend, sims[1].backend
+        bufs = [x.new_plane_buffer(2) for x in (a, b)]
+        a.plane_read(_lib.PLANE_HIGH_OWNED, bufs[0][0]); a.plane_read(_lib.PLANE_HIGH_HALO, bufs[0][1])
+        b.plane_read(_lib.PLANE_LOW_HALO, bufs[1][0]); b.plane_read(_lib.PLANE_LOW_OWNED, bufs[1][1])
+        torch.cuda.synchronize()
+        a.plane_add(_lib.PLANE_HIGH_OWNED, bufs[1][0], mask); a.plane_add(_lib.PLANE_HIGH_HALO, bufs[1][1], mask)
+        b.plane_add(_lib.PLANE_LOW_HALO, bufs[0][0], mask); b.plane_add(_lib.PLANE_LOW_OWNED, bufs[0][1], mask)
+        torch.cuda.synchronize()
+
+    moved = 0
+    for k in range(steps):
+        for s in sims:
+            s.set_uniforms(**dict(DEFAULT_UNIFORMS, time=0.25 * k))
+            s.backend.run_kernel(_lib.KERNEL_CLEAR_GRID)
+            s.backend.run_kernel(_lib.KERNEL_P2G1)
+        exchange(_lib.COMP_MASS)
+        for s in sims:
+            s.backend.run_kernel(_lib.KERNEL_P2G2)
+        exchange(_lib.COMP_MOMENTUM)
+        for s in sims:
+            s.backend.run_kernel(_lib.KERNEL_UPDATE_GRID)
+            s.backend.run_kernel(_lib.KERNEL_G2P)
+        out = [s.backend.extract_leavers(starts) for s in sims]
+        torch.cuda.synchronize()
+        for r, (counts, packed) in enumerate(out):
+            assert counts[r] == 0
+            if counts[1 - r]:
+                moved += int(counts[1 - r])
+                sims[1 - r].backend.insert_arrivals(packed.clone())
+        torch.cuda.synchronize()
+    assert moved > 0
+
+    want = rec.copy()
+    orc = oracle_binding.Oracle(grid)
+    for k in range(steps):
+        orc.step(want, oracle_binding.make_uniforms(grid, n, **dict(DEFAULT_UNIFORMS, time=0.25 * k)))
+    per = grid[1] * grid[2]
+    total = 0
+    for r, s in enumerate(sims):
+        got, ids = s.download()
+        total += got.shape[0]
+        assert_bits_equal(got, want[ids], "slab %d particles" % r)
+        x0, x1 = starts[r], starts[r + 1]
+        cell = s.backend.handle.download_grid_i32()[per:(x1 - x0 + 1) * per]
+        assert np.array_equal(cell, orc.cell[x0 * per:x1 * per]), "slab %d grid" % r
+        s.close()
+    assert total == n
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_on_one_gpu(oracle_binding, tmp_path):
+    """Two processes, both on cuda:0, gloo transport with host staging: the whole
+    SlabSimulation code path of the multi-GPU benchmark except RCCL itself."""
+    grid, n, steps, vel = (24, 16, 12), 4000, 8, 3.0
+    _launch(2, tmp_path, "--backend", "gpu", "--grid", "24,16,12", "--particles", str(n),
+            "--steps", str(steps), "--vel", str(vel))
+    rec, orc = _reference_run(oracle_binding, grid, n, steps, vel)
+    moved = _check_against_single_domain(tmp_path, 2, rec, orc, grid)
+    assert moved > 0
