@@ -43,6 +43,7 @@ class Config(ctypes.Structure):
         ("rebin_interval", ctypes.c_int32),
         ("max_particles", ctypes.c_int64),
         ("stream", ctypes.c_void_p),
+        ("external_stream", ctypes.c_int32),
     ]
 
 

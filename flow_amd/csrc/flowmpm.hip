@@ -388,7 +388,7 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
     int rc = FLOWMPM_OK;
     auto body = [&]() -> int {
         HIP_TRY(s, hipSetDevice(c.device));
-        if (c.stream) {
+        if (c.external_stream) {
             s->stream = reinterpret_cast<hipStream_t>(c.stream);
         } else {
             HIP_TRY(s, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));

@@ -33,7 +33,7 @@ class Handle:
     """One flowmpm_sim.  Every method maps to one C entry point."""
 
     def __init__(self, grid, max_particles, device=0, algorithm=_lib.ALGO_TILED, rebin_interval=1,
-                 slab=None, stream=None):
+                 slab=None, stream=None, external_stream=False):
         self.L = _lib.load()
         cfg = _lib.Config()
         cfg.grid_x, cfg.grid_y, cfg.grid_z = (int(g) for g in grid)
@@ -43,6 +43,7 @@ class Handle:
         cfg.rebin_interval = int(rebin_interval)
         cfg.max_particles = int(max_particles)
         cfg.stream = stream
+        cfg.external_stream = 1 if external_stream else 0
         self.grid = (cfg.grid_x, cfg.grid_y, cfg.grid_z)
         self.max_particles = int(max_particles)
         self.slab = slab

@@ -104,7 +104,8 @@ class GpuSlabBackend:
         torch.cuda.set_device(self.torch_device)
         stream = torch.cuda.current_stream(self.torch_device).cuda_stream
         self.handle = Handle(grid, max_particles, device=device, algorithm=algorithm,
-                             rebin_interval=rebin_interval, slab=(slab_x0, slab_nx), stream=stream)
+                             rebin_interval=rebin_interval, slab=(slab_x0, slab_nx), stream=stream,
+                             external_stream=True)
         self.plane_words = grid[1] * grid[2] * 4
         self.max_particles = max_particles
         self._leavers = torch.empty((max(max_particles // 4, 1024), RECORD_WORDS), dtype=torch.float32,

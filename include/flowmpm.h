@@ -87,8 +87,9 @@ typedef struct {
     int32_t algorithm;                /* FLOWMPM_ALGO_* */
     int32_t rebin_interval;           /* tiled: re-bin particles every k steps (>= 1) */
     int64_t max_particles;            /* conf.maxParticles, src/conf.js:8 */
-    void   *stream;                   /* hipStream_t to enqueue on, or NULL for a
-                                         stream owned by the handle */
+    void   *stream;                   /* hipStream_t to enqueue on when external_stream != 0
+                                         (NULL is then the device's default stream) */
+    int32_t external_stream;          /* 0: the handle creates and owns its stream */
 } flowmpm_config;
 
 /* The uniforms the hot path reads (SIM:141-151, 256-260) plus the clock that
