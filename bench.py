@@ -34,8 +34,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--algorithm", choices=("tiled", "scatter"), default="tiled")
-    ap.add_argument("--rebin-interval", type=int, default=1)
+    ap.add_argument("--algorithm", choices=("tiled", "tiled_unfused", "scatter"), default="tiled")
+    ap.add_argument("--rebin-interval", type=int, default=8)
     ap.add_argument("--particles-log2", type=int, default=24, help="particles per GPU = 2^k")
     ap.add_argument("--grid", type=str, default="", help="override the N=1 grid, e.g. 128,128,128")
     ap.add_argument("--scene", choices=("ellipsoid", "dam_break"), default="ellipsoid")
@@ -82,18 +82,29 @@ def cpu_baseline(rec, n, grid, uniforms, steps):
 
 
 def roofline_of(timings, n, cells):
-    """Roofline entry of the kernel with the largest share of the step."""
+    """Roofline entry of the kernel with the largest share of the step.  The tiled path runs
+    p2g1 + p2g2 as a mass pass and a summed-momentum pass, which moves work (and bytes) from the
+    first launch to the second, so the two are judged together as "p2g": algorithmic bytes of
+    both (116 N + 32 G) over the sum of their average launch durations."""
     best, out = None, {}
+    avg = {}
     for name, (bp, bc) in BYTES.items():
         t = timings[name]
         if t["launches"] == 0:
             continue
-        avg_ms = t["ms"] / t["launches"]
-        gbs = (bp * n + bc * cells) / (avg_ms * 1e-3) / 1e9
-        out[name] = {"avg_ms": round(avg_ms, 4), "algorithmic_GBs": round(gbs, 1),
+        avg[name] = t["ms"] / t["launches"]
+        gbs = (bp * n + bc * cells) / (avg[name] * 1e-3) / 1e9
+        out[name] = {"avg_ms": round(avg[name], 4), "algorithmic_GBs": round(gbs, 1),
                      "frac": round(gbs / HBM_PEAK_GBS, 4)}
-        if best is None or avg_ms > best[1]:
-            best = (name, avg_ms, gbs)
+    candidates = {k: (avg[k], (BYTES[k][0] * n + BYTES[k][1] * cells)) for k in avg if k not in ("p2g1", "p2g2")}
+    if "p2g1" in avg and "p2g2" in avg:
+        candidates["p2g"] = (avg["p2g1"] + avg["p2g2"], 116 * n + 32 * cells)
+        out["p2g"] = {"avg_ms": round(candidates["p2g"][0], 4),
+                      "algorithmic_GBs": round(candidates["p2g"][1] / (candidates["p2g"][0] * 1e-3) / 1e9, 1)}
+        out["p2g"]["frac"] = round(out["p2g"]["algorithmic_GBs"] / HBM_PEAK_GBS, 4)
+    for name, (ms, nbytes) in candidates.items():
+        if best is None or ms > best[1]:
+            best = (name, ms, nbytes / (ms * 1e-3) / 1e9)
     name, avg_ms, gbs = best
     roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4)}
@@ -108,7 +119,7 @@ def run_single(args):
     cells = grid[0] * grid[1] * grid[2]
     seed = 0xF10E5EED + 3
     uniforms = scene_uniforms(n, cells, args.scene)
-    algo = _lib.ALGO_TILED if args.algorithm == "tiled" else _lib.ALGO_SCATTER
+    algo = {"tiled": _lib.ALGO_TILED, "tiled_unfused": _lib.ALGO_TILED_UNFUSED, "scatter": _lib.ALGO_SCATTER}[args.algorithm]
     h = flow_amd.Handle(grid, n, device=0, algorithm=algo, rebin_interval=args.rebin_interval)
     rec = make_particles(args.scene, n, grid, seed)
     h.upload_particles(rec)
@@ -164,7 +175,7 @@ def run_distributed(args):
     cells = grid[0] * grid[1] * grid[2]
     seed = 0xF10E5EED + 4
     uniforms = scene_uniforms(n_total, cells, args.scene)
-    algo = _lib.ALGO_TILED if args.algorithm == "tiled" else _lib.ALGO_SCATTER
+    algo = {"tiled": _lib.ALGO_TILED, "tiled_unfused": _lib.ALGO_TILED_UNFUSED, "scatter": _lib.ALGO_SCATTER}[args.algorithm]
 
     # Every rank generates the id range [rank*n_per, (rank+1)*n_per) of the global scene; the
     # slab boundaries are chosen so that every slab starts with about the same particle count.

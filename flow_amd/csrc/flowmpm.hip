@@ -175,15 +175,16 @@ int stage_clear_grid(flowmpm_sim *s)
 }
 
 int stage_rebin_if_needed(flowmpm_sim *s);
+inline bool is_tiled(const flowmpm_sim *s);
 
 int stage_p2g1(flowmpm_sim *s)
 {
     int rc;
-    if (s->cfg.algorithm == FLOWMPM_ALGO_TILED && (rc = stage_rebin_if_needed(s))) return rc;
+    if (is_tiled(s) && (rc = stage_rebin_if_needed(s))) return rc;
     size_t t;
     if ((rc = timing_begin(s, FLOWMPM_KERNEL_P2G1, &t))) return rc;
     if (s->live > 0) {
-        if (s->cfg.algorithm == FLOWMPM_ALGO_TILED) {
+        if (is_tiled(s)) {
             if ((rc = mpm::launch_p2g1_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream)))
                 return fail(s, FLOWMPM_ERR_HIP, "p2g1_tiled launch failed");
         } else {
@@ -198,11 +199,11 @@ int stage_p2g1(flowmpm_sim *s)
 int stage_p2g2(flowmpm_sim *s)
 {
     int rc;
-    if (s->cfg.algorithm == FLOWMPM_ALGO_TILED && (rc = stage_rebin_if_needed(s))) return rc;
+    if (is_tiled(s) && (rc = stage_rebin_if_needed(s))) return rc;
     size_t t;
     if ((rc = timing_begin(s, FLOWMPM_KERNEL_P2G2, &t))) return rc;
     if (s->live > 0) {
-        if (s->cfg.algorithm == FLOWMPM_ALGO_TILED) {
+        if (is_tiled(s)) {
             if ((rc = mpm::launch_p2g2_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream)))
                 return fail(s, FLOWMPM_ERR_HIP, "p2g2_tiled launch failed");
         } else {
@@ -210,6 +211,24 @@ int stage_p2g2(flowmpm_sim *s)
                                s->stream, s->store, s->live, reinterpret_cast<int *>(s->cell), s->params);
         }
         if ((rc = launch_check(s, "p2g2"))) return rc;
+    }
+    return timing_end(s, t);
+}
+
+inline bool is_tiled(const flowmpm_sim *s) { return s->cfg.algorithm != FLOWMPM_ALGO_SCATTER; }
+
+// The two-pass p2g of the tiled algorithm; `momentum` selects the pass.
+int stage_p2g_pass(flowmpm_sim *s, bool momentum)
+{
+    int rc;
+    if (!is_tiled(s)) return fail(s, FLOWMPM_ERR_INVALID, "the mass/momentum passes belong to the tiled algorithm");
+    if ((rc = stage_rebin_if_needed(s))) return rc;
+    size_t t;
+    if ((rc = timing_begin(s, momentum ? FLOWMPM_KERNEL_P2G2 : FLOWMPM_KERNEL_P2G1, &t))) return rc;
+    if (s->live > 0) {
+        if (momentum) mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream);
+        else mpm::launch_p2g_mass_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream);
+        if ((rc = launch_check(s, momentum ? "p2g_momentum" : "p2g_mass"))) return rc;
     }
     return timing_end(s, t);
 }
@@ -229,11 +248,11 @@ int stage_update_grid(flowmpm_sim *s)
 int stage_g2p(flowmpm_sim *s)
 {
     int rc;
-    if (s->cfg.algorithm == FLOWMPM_ALGO_TILED && (rc = stage_rebin_if_needed(s))) return rc;
+    if (is_tiled(s) && (rc = stage_rebin_if_needed(s))) return rc;
     size_t t;
     if ((rc = timing_begin(s, FLOWMPM_KERNEL_G2P, &t))) return rc;
     if (s->live > 0) {
-        if (s->cfg.algorithm == FLOWMPM_ALGO_TILED) {
+        if (is_tiled(s)) {
             if ((rc = mpm::launch_g2p_tiled(s->tiled, s->store, s->live, s->cellf, s->params, s->stream)))
                 return fail(s, FLOWMPM_ERR_HIP, "g2p_tiled launch failed");
             s->tiled.steps_since_rebin += 1;
@@ -365,7 +384,8 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         return fail(nullptr, FLOWMPM_ERR_INVALID, "grid too large for 32-bit cell indexing");
     if (c.max_particles < 0 || c.max_particles > 2147483647LL)
         return fail(nullptr, FLOWMPM_ERR_INVALID, "max_particles out of range");
-    if (c.algorithm != FLOWMPM_ALGO_SCATTER && c.algorithm != FLOWMPM_ALGO_TILED)
+    if (c.algorithm != FLOWMPM_ALGO_SCATTER && c.algorithm != FLOWMPM_ALGO_TILED &&
+        c.algorithm != FLOWMPM_ALGO_TILED_UNFUSED)
         return fail(nullptr, FLOWMPM_ERR_INVALID, "unknown algorithm");
     if (c.slab_nx < 0 || c.slab_x0 < 0 || c.slab_x0 + c.slab_nx > c.grid_x)
         return fail(nullptr, FLOWMPM_ERR_INVALID, "slab outside the grid");
@@ -402,7 +422,7 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         HIP_TRY(s, hipMemsetAsync(s->cellf, 0, (size_t)s->local_cells * sizeof(float4), s->stream));
         int r = alloc_store(s, &s->store);
         if (r) return r;
-        if (c.algorithm == FLOWMPM_ALGO_TILED) {
+        if (c.algorithm != FLOWMPM_ALGO_SCATTER) {
             if ((r = alloc_store(s, &s->store_alt))) return r;
             std::string msg;
             if (mpm::tiled_init(s->tiled, s->params, s->capacity, s->stream, &msg))
@@ -486,6 +506,8 @@ int flowmpm_run_kernel(flowmpm_sim *s, int32_t kernel_id)
     case FLOWMPM_KERNEL_P2G2: return stage_p2g2(s);
     case FLOWMPM_KERNEL_UPDATE_GRID: return stage_update_grid(s);
     case FLOWMPM_KERNEL_G2P: return stage_g2p(s);
+    case FLOWMPM_KERNEL_P2G_MASS: return stage_p2g_pass(s, false);
+    case FLOWMPM_KERNEL_P2G_MOMENTUM: return stage_p2g_pass(s, true);
     default: return fail(s, FLOWMPM_ERR_INVALID, "unknown kernel id");
     }
 }
@@ -499,8 +521,13 @@ int flowmpm_step(flowmpm_sim *s, int32_t n_steps, double dtime)
     for (int k = 0; k < n_steps && rc == FLOWMPM_OK; k++) {
         s->params.time = (float)((double)time0 + (double)k * dtime);
         if ((rc = stage_clear_grid(s))) break;
-        if ((rc = stage_p2g1(s))) break;
-        if ((rc = stage_p2g2(s))) break;
+        if (s->cfg.algorithm == FLOWMPM_ALGO_TILED) {
+            if ((rc = stage_p2g_pass(s, false))) break;
+            if ((rc = stage_p2g_pass(s, true))) break;
+        } else {
+            if ((rc = stage_p2g1(s))) break;
+            if ((rc = stage_p2g2(s))) break;
+        }
         if ((rc = stage_update_grid(s))) break;
         if ((rc = stage_g2p(s))) break;
         // bound the number of live event pairs

@@ -23,9 +23,15 @@
 
 namespace mpm {
 
-// Tile shape in cells.  The arena adds one cell on every side.
+// Tile shape in cells.
 constexpr int kTX = 8, kTY = 8, kTZ = 8;
-constexpr int kAX = kTX + 2, kAY = kTY + 2, kAZ = kTZ + 2;
+// Rim of the arena in cells: 1 is what the stencil of a freshly binned particle needs; every
+// cell beyond that is drift a stale bin tolerates before its particle falls back to global atomics.
+#ifndef FLOWMPM_RIM
+#define FLOWMPM_RIM 2
+#endif
+constexpr int kRim = FLOWMPM_RIM;
+constexpr int kAX = kTX + 2 * kRim, kAY = kTY + 2 * kRim, kAZ = kTZ + 2 * kRim;
 constexpr int kArenaCells = kAX * kAY * kAZ;
 constexpr int kArenaPad = kArenaCells + 8;     // component stride in LDS (dwords)
 constexpr int kChunk = 4096;                   // most particles one work item holds
@@ -146,7 +152,7 @@ __device__ __forceinline__ Arena arena_of_tile(int tile, TileDims td, const Para
     int tz = tile % td.tiles_z;
     int ty = (tile / td.tiles_z) % td.tiles_y;
     int tx = tile / (td.tiles_z * td.tiles_y);
-    return Arena{tx * kTX + P.x_off - 1, ty * kTY - 1, tz * kTZ - 1};
+    return Arena{tx * kTX + P.x_off - kRim, ty * kTY - kRim, tz * kTZ - kRim};
 }
 
 __device__ __forceinline__ int arena_index(int ax, int ay, int az) { return (ax * kAY + ay) * kAZ + az; }
@@ -349,6 +355,169 @@ p2g2_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restric
     flush_arena<3>(lds, A, P, cell);
 }
 
+// ---- fused p2g: mass pass + momentum pass --------------------------------------------
+//
+// p2g1 and p2g2 together perform 27 x (4 + 3) atomic adds per particle.  The momentum
+// words of p2g1 are not read by anything before updateGrid, and integer addition is
+// associative, so the step is free to add encode(p2g1 momentum) and encode(p2g2 momentum)
+// of one (particle, cell) pair in a register and issue ONE atomic for the sum -- as long
+// as each term is still encoded on its own first (SIM:279-281, 326-328, 386-388).  That
+// gives a mass-only first pass (27 adds, reads position only) and a second pass with
+// 27 x 3 adds: 108 instead of 189 LDS atomics per particle, and the grid after the second
+// pass is bit-identical to the grid after the reference's p2g2.  The grid between the two
+// passes differs from the reference's (momentum not yet present), so flowmpm_run_kernel
+// keeps the unfused kernels above for stage-by-stage parity.
+
+__device__ __forceinline__ int add_wrap(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+
+template <bool INSIDE>
+__device__ __forceinline__ void p2g_mass_particle(const Stencil &s, int *lds, int abase, int *__restrict__ cell,
+                                                  const Params &P)
+{
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                int em = encode_fixed(wxy * s.wz[gz]);
+                if (INSIDE) {
+                    atomicAdd(&lds[abase + arena_index(gx, gy, gz)], em);
+                } else {
+                    long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                    if (c >= 0) atomicAdd(cell + 4 * c + 3, em);
+                }
+            }
+        }
+}
+
+__global__ void __launch_bounds__(kTiledThreads)
+p2g_mass_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
+                      TileDims td, int *__restrict__ cell, Params P)
+{
+    if ((int)blockIdx.x >= *n_items) return;
+    __shared__ int lds[kArenaCells];
+    const int4 item = items[blockIdx.x];
+    const Arena A = arena_of_tile(item.x, td, P);
+    for (int i = threadIdx.x; i < kArenaCells; i += kTiledThreads) lds[i] = 0;
+    __syncthreads();
+    for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
+        Stencil s = make_stencil(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j]);
+        int abase;
+        if (stencil_in_arena(s, A, &abase))
+            p2g_mass_particle<true>(s, lds, abase, cell, P);
+        else
+            p2g_mass_particle<false>(s, lds, abase, cell, P);
+    }
+    __syncthreads();
+    for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
+        int v = lds[a];
+        if (v == 0) continue;
+        long long c = arena_cell_to_grid(a, A, P);
+        if (c >= 0) atomicAdd(cell + 4 * c + 3, v);
+    }
+}
+
+template <bool INSIDE>
+__device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx, float vy, float vz,
+                                                      const float C[9], float *dens_slot, int *lds,
+                                                      const float *mass_f, int abase, int *__restrict__ cell,
+                                                      const Params &P)
+{
+    float density = 0.0f;
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                float m;
+                if (INSIDE) {
+                    m = mass_f[abase + arena_index(gx, gy, gz)];
+                } else {
+                    long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                    m = decode_fixed((c >= 0) ? cell[4 * c + 3] : 0);
+                }
+                density = density + m * weight;
+            }
+        }
+    *dens_slot = *dens_slot * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
+    Eq16 e = p2g2_stress(density, C, P);
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                float dx = s.dx[gx], dy = s.dy[gy], dz = s.dz[gz];
+                // p2g1's velContrib (SIM:321-328)
+                float qx = (C[0] * dx + C[3] * dy) + C[6] * dz;
+                float qy = (C[1] * dx + C[4] * dy) + C[7] * dz;
+                float qz = (C[2] * dx + C[5] * dy) + C[8] * dz;
+                int ex = encode_fixed(weight * (vx + qx));
+                int ey = encode_fixed(weight * (vy + qy));
+                int ez = encode_fixed(weight * (vz + qz));
+                // p2g2's momentum (SIM:385-388)
+                float a00 = e.m00 * weight, a11 = e.m11 * weight, a22 = e.m22 * weight;
+                float a01 = e.m01 * weight, a02 = e.m02 * weight, a12 = e.m12 * weight;
+                ex = add_wrap(ex, encode_fixed((a00 * dx + a01 * dy) + a02 * dz));
+                ey = add_wrap(ey, encode_fixed((a01 * dx + a11 * dy) + a12 * dz));
+                ez = add_wrap(ez, encode_fixed((a02 * dx + a12 * dy) + a22 * dz));
+                if (INSIDE) {
+                    int a = abase + arena_index(gx, gy, gz);
+                    atomicAdd(&lds[0 * kArenaPad + a], ex);
+                    atomicAdd(&lds[1 * kArenaPad + a], ey);
+                    atomicAdd(&lds[2 * kArenaPad + a], ez);
+                } else {
+                    long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
+                    if (c >= 0) {
+                        atomicAdd(cell + 4 * c + 0, ex);
+                        atomicAdd(cell + 4 * c + 1, ey);
+                        atomicAdd(cell + 4 * c + 2, ez);
+                    }
+                }
+            }
+        }
+}
+
+__global__ void __launch_bounds__(kTiledThreads)
+p2g_momentum_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
+                          TileDims td, int *__restrict__ cell, Params P)
+{
+    if ((int)blockIdx.x >= *n_items) return;
+    __shared__ int lds[3 * kArenaPad];
+    __shared__ float mass_f[kArenaCells];
+    const int4 item = items[blockIdx.x];
+    const Arena A = arena_of_tile(item.x, td, P);
+    for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
+    for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
+        long long c = arena_cell_to_grid(a, A, P);
+        mass_f[a] = decode_fixed((c >= 0) ? cell[4 * c + 3] : 0);
+    }
+    __syncthreads();
+    float *dens = st.slot(kDensity);
+    for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
+        float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
+        float vx = st.slot(kVelX)[j], vy = st.slot(kVelY)[j], vz = st.slot(kVelZ)[j];
+        float C[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) C[k] = st.slot(kC00 + k)[j];
+        Stencil s = make_stencil(px, py, pz);
+        int abase;
+        if (stencil_in_arena(s, A, &abase))
+            p2g_momentum_particle<true>(s, vx, vy, vz, C, dens + j, lds, mass_f, abase, cell, P);
+        else
+            p2g_momentum_particle<false>(s, vx, vy, vz, C, dens + j, lds, mass_f, abase, cell, P);
+    }
+    __syncthreads();
+    flush_arena<3>(lds, A, P, cell);
+}
+
 // ---- g2p (SIM:431-1536, chaos path) -----------------------------------------------
 
 template <bool INSIDE>
@@ -493,6 +662,21 @@ inline int launch_p2g1_tiled(TiledState &T, Store st, long long n, int4 *cell, c
 inline int launch_p2g2_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P, hipStream_t stream)
 {
     hipLaunchKernelGGL(p2g2_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
+                       T.n_items, tile_dims(T), reinterpret_cast<int *>(cell), P);
+    return 0;
+}
+
+inline int launch_p2g_mass_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P, hipStream_t stream)
+{
+    hipLaunchKernelGGL(p2g_mass_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
+                       T.n_items, tile_dims(T), reinterpret_cast<int *>(cell), P);
+    return 0;
+}
+
+inline int launch_p2g_momentum_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P,
+                                     hipStream_t stream)
+{
+    hipLaunchKernelGGL(p2g_momentum_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
                        T.n_items, tile_dims(T), reinterpret_cast<int *>(cell), P);
     return 0;
 }

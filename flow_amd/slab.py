@@ -165,6 +165,11 @@ class SlabSimulation:
         self.backend = backend if backend is not None else GpuSlabBackend(
             self.grid, self.x0, self.nx, max_particles, device, algorithm, rebin_interval)
         self.transport = _Transport(dist) if (dist is not None and world > 1) else None
+        # the tiled algorithm's two-pass p2g (mass, then summed momentum); other backends keep
+        # the reference's p2g1 / p2g2
+        fused = backend is None and algorithm == _lib.ALGO_TILED
+        self.p2g_kernels = ((_lib.KERNEL_P2G_MASS, _lib.KERNEL_P2G_MOMENTUM) if fused
+                            else (_lib.KERNEL_P2G1, _lib.KERNEL_P2G2))
         self.low = rank - 1 if rank > 0 else None
         self.high = rank + 1 if rank < world - 1 else None
         b = self.backend
@@ -276,10 +281,11 @@ class SlabSimulation:
 
     def step(self):
         b = self.backend
+        p2g = self.p2g_kernels
         b.run_kernel(_lib.KERNEL_CLEAR_GRID)
-        b.run_kernel(_lib.KERNEL_P2G1)
+        b.run_kernel(p2g[0])
         self._exchange_planes(_lib.COMP_MASS)
-        b.run_kernel(_lib.KERNEL_P2G2)
+        b.run_kernel(p2g[1])
         self._exchange_planes(_lib.COMP_MOMENTUM)
         b.run_kernel(_lib.KERNEL_UPDATE_GRID)
         b.run_kernel(_lib.KERNEL_G2P)

@@ -42,6 +42,12 @@ extern "C" {
 #define FLOWMPM_KERNEL_UPDATE_GRID  3   /* SIM:395-429  */
 #define FLOWMPM_KERNEL_G2P          4   /* SIM:431-1536 (chaos path) */
 #define FLOWMPM_KERNEL_COUNT        5
+/* The tiled algorithm's two-pass form of p2g1 + p2g2 (no reference counterpart one by one:
+ * MASS adds only the mass words of SIM:329; MOMENTUM adds, per particle and cell, the sum of
+ * the separately encoded momentum words of SIM:326-328 and SIM:386-388).  After both, the
+ * grid equals the reference's grid after p2g2 bit for bit.  flowmpm_step uses this form. */
+#define FLOWMPM_KERNEL_P2G_MASS     16
+#define FLOWMPM_KERNEL_P2G_MOMENTUM 17
 
 /* Timing slots reported by flowmpm_get_timings: the five kernels, then the
  * particle re-binning pass of the tiled algorithm (no reference counterpart). */
@@ -52,7 +58,10 @@ extern "C" {
 #define FLOWMPM_ALGO_SCATTER 0   /* the reference's algorithm: one thread per particle,
                                     27 x 4 global i32 atomics (SIM:315-331) */
 #define FLOWMPM_ALGO_TILED   1   /* particles binned by grid tile, contributions summed
-                                    as fixed-point integers in LDS, one flush per tile */
+                                    as fixed-point integers in LDS, one flush per tile;
+                                    flowmpm_step runs p2g as the MASS + MOMENTUM passes */
+#define FLOWMPM_ALGO_TILED_UNFUSED 2  /* same, but flowmpm_step keeps p2g1 and p2g2 as the
+                                    reference stages them (for A/B measurements) */
 
 /* Per-particle fields for flowmpm_download_field (what the reference's renderers
  * read from the particle buffer: src/mls-mpm/particleRenderer.js:119-133,
