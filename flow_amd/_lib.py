@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflowmpm.so")
+# FLOWMPM_LIBRARY points experiments at an alternative build of the same library.
+LIB_PATH = os.environ.get("FLOWMPM_LIBRARY") or os.path.join(_HERE, "lib", "libflowmpm.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_CAPACITY = 0, 1, 2, 3, 4
 PARTICLE_STRIDE = 28

@@ -226,8 +226,9 @@ int stage_p2g_pass(flowmpm_sim *s, bool momentum)
     size_t t;
     if ((rc = timing_begin(s, momentum ? FLOWMPM_KERNEL_P2G2 : FLOWMPM_KERNEL_P2G1, &t))) return rc;
     if (s->live > 0) {
-        if (momentum) mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream);
-        else mpm::launch_p2g_mass_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream);
+        rc = momentum ? mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream)
+                      : mpm::launch_p2g_mass_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream);
+        if (rc) return fail(s, FLOWMPM_ERR_HIP, "p2g pass: could not reset the straggler counter");
         if ((rc = launch_check(s, momentum ? "p2g_momentum" : "p2g_mass"))) return rc;
     }
     return timing_end(s, t);

@@ -36,6 +36,34 @@ constexpr int kArenaCells = kAX * kAY * kAZ;
 constexpr int kArenaPad = kArenaCells + 8;     // component stride in LDS (dwords)
 constexpr int kChunk = 4096;                   // most particles one work item holds
 constexpr int kTiledThreads = 256;
+// Minimum waves per SIMD the register allocator must leave room for (second argument of
+// __launch_bounds__) in the two register-heavy kernels; measured, not guessed.
+#ifndef FLOWMPM_P2G_WAVES
+#define FLOWMPM_P2G_WAVES 1
+#endif
+#ifndef FLOWMPM_G2P_WAVES
+#define FLOWMPM_G2P_WAVES 1
+#endif
+#ifndef FLOWMPM_SLAB_FENCE
+#define FLOWMPM_SLAB_FENCE 1
+#endif
+// Software prefetch of the next particle's fields: neutral to slightly positive in g2p,
+// negative in the momentum pass (15 more VGPRs cost a wave per SIMD).
+#ifndef FLOWMPM_PREFETCH_G2P
+#define FLOWMPM_PREFETCH_G2P 1
+#endif
+#ifndef FLOWMPM_PREFETCH_P2G
+#define FLOWMPM_PREFETCH_P2G 0
+#endif
+
+// Particles whose stencil no longer fits their bin's arena (they drifted since the last
+// re-bin) are not handled by the tiled kernels: their slot index is appended here and a
+// small follow-up kernel sends their contributions straight to the global grid.  Keeping
+// that rare path out of the hot kernels keeps their register allocation small.
+struct Stragglers {
+    int *count;     // device scalar, zeroed before every tiled launch
+    int *list;      // slot indices, capacity = store capacity
+};
 
 struct TiledState {
     bool valid = false;
@@ -48,6 +76,7 @@ struct TiledState {
     int *tile_start = nullptr;   // [n_tiles + 1]
     int4 *items = nullptr;       // work items {tile, begin, end, 0}
     int *n_items = nullptr;      // device scalar
+    Stragglers stragglers{nullptr, nullptr};
 };
 
 struct TileDims { int tiles_x, tiles_y, tiles_z; };
@@ -164,6 +193,11 @@ __device__ __forceinline__ long long arena_cell_to_grid(int a, const Arena &A, c
     return local_cell(A.ox + ax, A.oy + ay, A.oz + az, P);
 }
 
+__device__ __forceinline__ void add_straggler(const Stragglers &sg, int j)
+{
+    sg.list[atomicAdd(sg.count, 1)] = j;
+}
+
 // Adds every non-zero word of an LDS arena component to the global grid.  A wave
 // instruction covers (component, consecutive cells) so that its 64 atomics fall
 // in runs of contiguous 16-byte cell records.
@@ -236,7 +270,7 @@ __device__ __forceinline__ bool stencil_in_arena(const Stencil &s, const Arena &
 
 __global__ void __launch_bounds__(kTiledThreads)
 p2g1_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                  TileDims td, int *__restrict__ cell, Params P)
+                  TileDims td, int *__restrict__ cell, Params P, Stragglers sg)
 {
     if ((int)blockIdx.x >= *n_items) return;
     __shared__ int lds[4 * kArenaPad];
@@ -256,7 +290,7 @@ p2g1_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restric
         if (stencil_in_arena(s, A, &abase))
             p2g1_particle<true>(s, vx, vy, vz, C, lds, abase, cell, P);
         else
-            p2g1_particle<false>(s, vx, vy, vz, C, lds, abase, cell, P);
+            add_straggler(sg, j);
     }
     __syncthreads();
     flush_arena<4>(lds, A, P, cell);
@@ -323,7 +357,7 @@ __device__ __forceinline__ void p2g2_particle(const Stencil &s, const float C[9]
 
 __global__ void __launch_bounds__(kTiledThreads)
 p2g2_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                  TileDims td, int *__restrict__ cell, Params P)
+                  TileDims td, int *__restrict__ cell, Params P, Stragglers sg)
 {
     if ((int)blockIdx.x >= *n_items) return;
     __shared__ int lds[3 * kArenaPad];
@@ -349,7 +383,7 @@ p2g2_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restric
         if (stencil_in_arena(s, A, &abase))
             p2g2_particle<true>(s, C, dens + j, lds, mass_f, abase, cell, P);
         else
-            p2g2_particle<false>(s, C, dens + j, lds, mass_f, abase, cell, P);
+            add_straggler(sg, j);
     }
     __syncthreads();
     flush_arena<3>(lds, A, P, cell);
@@ -394,7 +428,7 @@ __device__ __forceinline__ void p2g_mass_particle(const Stencil &s, int *lds, in
 
 __global__ void __launch_bounds__(kTiledThreads)
 p2g_mass_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                      TileDims td, int *__restrict__ cell, Params P)
+                      TileDims td, int *__restrict__ cell, Params P, Stragglers sg)
 {
     if ((int)blockIdx.x >= *n_items) return;
     __shared__ int lds[kArenaCells];
@@ -408,7 +442,7 @@ p2g_mass_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__res
         if (stencil_in_arena(s, A, &abase))
             p2g_mass_particle<true>(s, lds, abase, cell, P);
         else
-            p2g_mass_particle<false>(s, lds, abase, cell, P);
+            add_straggler(sg, j);
     }
     __syncthreads();
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
@@ -485,9 +519,9 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
         }
 }
 
-__global__ void __launch_bounds__(kTiledThreads)
+__global__ void __launch_bounds__(kTiledThreads, FLOWMPM_P2G_WAVES)
 p2g_momentum_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                          TileDims td, int *__restrict__ cell, Params P)
+                          TileDims td, int *__restrict__ cell, Params P, Stragglers sg)
 {
     if ((int)blockIdx.x >= *n_items) return;
     __shared__ int lds[3 * kArenaPad];
@@ -501,18 +535,39 @@ p2g_momentum_tiled_kernel(Store st, const int4 *__restrict__ items, const int *_
     }
     __syncthreads();
     float *dens = st.slot(kDensity);
-    for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
-        float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
-        float vx = st.slot(kVelX)[j], vy = st.slot(kVelY)[j], vz = st.slot(kVelZ)[j];
-        float C[9];
+    // Software pipeline: the next particle's 15 loads are issued before this particle's LDS
+    // atomics and density store, so an iteration never starts by waiting on memory.
+    float in[15];
+    int j = item.y + threadIdx.x;
+    if (j < item.z) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) C[k] = st.slot(kC00 + k)[j];
-        Stencil s = make_stencil(px, py, pz);
+        for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
+    }
+    while (j < item.z) {
+        const int jn = j + kTiledThreads;
+#if FLOWMPM_PREFETCH_P2G
+        float nx[15];
+        if (jn < item.z) {
+#pragma unroll
+            for (int k = 0; k < 15; k++) nx[k] = st.slot(kPosX + k)[jn];
+        }
+#endif
+        Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
         int abase;
         if (stencil_in_arena(s, A, &abase))
-            p2g_momentum_particle<true>(s, vx, vy, vz, C, dens + j, lds, mass_f, abase, cell, P);
+            p2g_momentum_particle<true>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + j, lds, mass_f, abase, cell, P);
         else
-            p2g_momentum_particle<false>(s, vx, vy, vz, C, dens + j, lds, mass_f, abase, cell, P);
+            add_straggler(sg, j);
+#if FLOWMPM_PREFETCH_P2G
+#pragma unroll
+        for (int k = 0; k < 15; k++) in[k] = nx[k];
+#else
+        if (jn < item.z) {
+#pragma unroll
+            for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[jn];
+        }
+#endif
+        j = jn;
     }
     __syncthreads();
     flush_arena<3>(lds, A, P, cell);
@@ -546,12 +601,16 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                 B[6] = B[6] + wvx * dz; B[7] = B[7] + wvy * dz; B[8] = B[8] + wvz * dz;
                 v.x = v.x + wvx; v.y = v.y + wvy; v.z = v.z + wvz;
             }
+#if FLOWMPM_SLAB_FENCE
+            // keep the compiler from hoisting all 27 arena reads (108 VGPRs) to the top
+            if (INSIDE) asm volatile("" ::: "memory");
+#endif
         }
 }
 
-__global__ void __launch_bounds__(kTiledThreads)
+__global__ void __launch_bounds__(kTiledThreads, FLOWMPM_G2P_WAVES)
 g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                 TileDims td, const float4 *__restrict__ cellf, Params P)
+                 TileDims td, const float4 *__restrict__ cellf, Params P, Stragglers sg)
 {
     if ((int)blockIdx.x >= *n_items) return;
     __shared__ float4 grid[kArenaCells];
@@ -563,7 +622,76 @@ g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict
     }
     __syncthreads();
 
-    for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
+    // Software pipeline: the next particle's loads are issued before this particle's 18 stores
+    // (the memory counter retires in order, so a load issued after them would wait for them).
+    G2PIn in, nx;
+    int j = item.y + threadIdx.x;
+    auto load = [&](G2PIn &r, int q) {
+        r.px = st.slot(kPosX)[q]; r.py = st.slot(kPosY)[q]; r.pz = st.slot(kPosZ)[q];
+        r.mass = st.slot(kMass)[q];
+        r.dirx = st.slot(kDirX)[q]; r.diry = st.slot(kDirY)[q]; r.dirz = st.slot(kDirZ)[q];
+    };
+    if (j < item.z) load(in, j);
+    while (j < item.z) {
+        const int jn = j + kTiledThreads;
+#if FLOWMPM_PREFETCH_G2P
+        if (jn < item.z) load(nx, jn);
+#endif
+        Stencil s = make_stencil(in.px, in.py, in.pz);
+        int abase;
+        if (stencil_in_arena(s, A, &abase)) {
+            Vec3 v = g2p_pre_forces(in.px, in.py, in.pz, P);
+            float B[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) B[k] = 0.0f;
+            g2p_gather<true>(s, grid, abase, cellf, P, v, B);
+            G2POut o = g2p_finish(in, v, B, P);
+#pragma unroll
+            for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
+            st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;
+            st.slot(kVelX)[j] = o.vx; st.slot(kVelY)[j] = o.vy; st.slot(kVelZ)[j] = o.vz;
+            st.slot(kDirX)[j] = o.dirx; st.slot(kDirY)[j] = o.diry; st.slot(kDirZ)[j] = o.dirz;
+        } else {
+            add_straggler(sg, j);
+        }
+#if FLOWMPM_PREFETCH_G2P
+        in = nx;
+#else
+        if (jn < item.z) load(in, jn);
+#endif
+        j = jn;
+    }
+}
+
+// ---- stragglers --------------------------------------------------------------------
+// One thread per listed particle, contributions straight to / from the global grids
+// (the reference's own access pattern).  PASS: 0 p2g1, 1 p2g2, 2 mass pass, 3 momentum pass.
+template <int PASS>
+__global__ void __launch_bounds__(256)
+straggler_p2g_kernel(Store st, Stragglers sg, int *__restrict__ cell, Params P)
+{
+    const int count = *sg.count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const int j = sg.list[i];
+        float in[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
+        Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
+        if (PASS == 0) p2g1_particle<false>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, nullptr, 0, cell, P);
+        if (PASS == 1) p2g2_particle<false>(s, in + kC00, st.slot(kDensity) + j, nullptr, nullptr, 0, cell, P);
+        if (PASS == 2) p2g_mass_particle<false>(s, nullptr, 0, cell, P);
+        if (PASS == 3)
+            p2g_momentum_particle<false>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, st.slot(kDensity) + j,
+                                         nullptr, nullptr, 0, cell, P);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+straggler_g2p_kernel(Store st, Stragglers sg, const float4 *__restrict__ cellf, Params P)
+{
+    const int count = *sg.count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const int j = sg.list[i];
         G2PIn in;
         in.px = st.slot(kPosX)[j]; in.py = st.slot(kPosY)[j]; in.pz = st.slot(kPosZ)[j];
         in.mass = st.slot(kMass)[j];
@@ -573,11 +701,7 @@ g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict
         float B[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) B[k] = 0.0f;
-        int abase;
-        if (stencil_in_arena(s, A, &abase))
-            g2p_gather<true>(s, grid, abase, cellf, P, v, B);
-        else
-            g2p_gather<false>(s, grid, abase, cellf, P, v, B);
+        g2p_gather<false>(s, nullptr, 0, cellf, P, v, B);
         G2POut o = g2p_finish(in, v, B, P);
 #pragma unroll
         for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
@@ -610,6 +734,8 @@ inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStr
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.items), (size_t)T.item_cap * sizeof(int4)), "hipMalloc items")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.n_items), sizeof(int)), "hipMalloc n_items")) return 1;
     if (chk(e = hipMemsetAsync(T.n_items, 0, sizeof(int), stream), "memset n_items")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.stragglers.count), 256), "hipMalloc straggler count")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.stragglers.list), (size_t)capacity * sizeof(int)), "hipMalloc straggler list")) return 1;
     T.valid = false;
     T.steps_since_rebin = 0;
     return 0;
@@ -623,6 +749,8 @@ inline void tiled_free(TiledState &T)
     if (T.tile_start) (void)hipFree(T.tile_start);
     if (T.items) (void)hipFree(T.items);
     if (T.n_items) (void)hipFree(T.n_items);
+    if (T.stragglers.count) (void)hipFree(T.stragglers.count);
+    if (T.stragglers.list) (void)hipFree(T.stragglers.list);
     T = TiledState{};
 }
 
@@ -652,41 +780,44 @@ inline unsigned item_bound(const TiledState &T, long long n)
     return (unsigned)std::max<long long>(b, 1);
 }
 
+// Every tiled stage is: zero the straggler counter, the tiled kernel, the straggler kernel.
+constexpr int kStragglerBlocks = 128;
+
+#define FLOWMPM_TILED_STAGE(kernel, straggler_kernel, grid_ptr)                                              \
+    do {                                                                                                    \
+        if (hipMemsetAsync(T.stragglers.count, 0, sizeof(int), stream) != hipSuccess) return 1;             \
+        hipLaunchKernelGGL(kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,     \
+                           T.n_items, tile_dims(T), grid_ptr, P, T.stragglers);                             \
+        hipLaunchKernelGGL(straggler_kernel, dim3(kStragglerBlocks), dim3(256), 0, stream, st, T.stragglers, \
+                           grid_ptr, P);                                                                    \
+        return 0;                                                                                           \
+    } while (0)
+
 inline int launch_p2g1_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P, hipStream_t stream)
 {
-    hipLaunchKernelGGL(p2g1_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
-                       T.n_items, tile_dims(T), reinterpret_cast<int *>(cell), P);
-    return 0;
+    FLOWMPM_TILED_STAGE(p2g1_tiled_kernel, straggler_p2g_kernel<0>, reinterpret_cast<int *>(cell));
 }
 
 inline int launch_p2g2_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P, hipStream_t stream)
 {
-    hipLaunchKernelGGL(p2g2_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
-                       T.n_items, tile_dims(T), reinterpret_cast<int *>(cell), P);
-    return 0;
+    FLOWMPM_TILED_STAGE(p2g2_tiled_kernel, straggler_p2g_kernel<1>, reinterpret_cast<int *>(cell));
 }
 
 inline int launch_p2g_mass_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P, hipStream_t stream)
 {
-    hipLaunchKernelGGL(p2g_mass_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
-                       T.n_items, tile_dims(T), reinterpret_cast<int *>(cell), P);
-    return 0;
+    FLOWMPM_TILED_STAGE(p2g_mass_tiled_kernel, straggler_p2g_kernel<2>, reinterpret_cast<int *>(cell));
 }
 
 inline int launch_p2g_momentum_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P,
                                      hipStream_t stream)
 {
-    hipLaunchKernelGGL(p2g_momentum_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
-                       T.n_items, tile_dims(T), reinterpret_cast<int *>(cell), P);
-    return 0;
+    FLOWMPM_TILED_STAGE(p2g_momentum_tiled_kernel, straggler_p2g_kernel<3>, reinterpret_cast<int *>(cell));
 }
 
 inline int launch_g2p_tiled(TiledState &T, Store st, long long n, const float4 *cellf, const Params &P,
                             hipStream_t stream)
 {
-    hipLaunchKernelGGL(g2p_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,
-                       T.n_items, tile_dims(T), cellf, P);
-    return 0;
+    FLOWMPM_TILED_STAGE(g2p_tiled_kernel, straggler_g2p_kernel, cellf);
 }
 
 }  // namespace mpm
