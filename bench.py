@@ -41,6 +41,10 @@ def parse_args():
     ap.add_argument("--scene", choices=("ellipsoid", "dam_break"), default="ellipsoid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="gloo = rehearsal of the multi-rank path on fewer GPUs than ranks (host-staged transport)")
+    ap.add_argument("--slab-yz", type=int, default=512, help="y and z extent of the multi-GPU domain")
+    ap.add_argument("--slab-x-per-gpu", type=int, default=64)
     return ap.parse_args()
 
 
@@ -166,12 +170,17 @@ def run_distributed(args):
     from flow_amd.slab import SlabSimulation, balanced_plane_starts
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    local_rank = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.dist_backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm_dev = torch.device("cuda", local_rank)
+    else:
+        dist.init_process_group("gloo")
+        comm_dev = torch.device("cpu")
     n_per = 1 << args.particles_log2
     n_total = n_per * world
-    grid = (64 * world, 512, 512)
+    grid = (args.slab_x_per_gpu * world, args.slab_yz, args.slab_yz)
     cells = grid[0] * grid[1] * grid[2]
     seed = 0xF10E5EED + 4
     uniforms = scene_uniforms(n_total, cells, args.scene)
@@ -198,10 +207,10 @@ def run_distributed(args):
     sim.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
-    resident = torch.tensor([sim.resident()], dtype=torch.int64, device="cuda")
+    resident = torch.tensor([sim.resident()], dtype=torch.int64, device=comm_dev)
     gathered = [torch.zeros_like(resident) for _ in range(world)]
     dist.all_gather(gathered, resident)
     line = None
@@ -212,8 +221,9 @@ def run_distributed(args):
             "unit": "particle-substeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32+i32-fixed-point", "data": "synthetic",
-            "config": {"workload": "%dM particles, %dx512x512 grid, %d x-slabs over %d MI355X (2^24 particles per GPU)"
-                                   % (n_total >> 20, grid[0], world, world),
+            "config": {"workload": "%d particles, %dx%dx%d grid, %d x-slabs over %d MI355X (%d particles per GPU)"
+                                   % (n_total, grid[0], grid[1], grid[2], world, world, n_per),
+                       "transport": args.dist_backend,
                        "scene": args.scene, "particles": n_total, "grid": list(grid), "algorithm": args.algorithm,
                        "rebin_interval": args.rebin_interval, "parallelism": "slab%d" % world,
                        "plane_starts": [int(s) for s in starts], "resident_per_rank_end": per_rank},

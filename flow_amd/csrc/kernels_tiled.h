@@ -158,14 +158,26 @@ bin_scan_kernel(const int *__restrict__ tile_count, int n_tiles, int *__restrict
     if (t == 0) { tile_start[n_tiles] = carry_cnt; *n_items_out = carry_itm; }
 }
 
-// Pass 3: move every particle record to its slot in the binned store.
+// Pass 3: where does each destination slot come from?  4 bytes per particle are scattered
+// (source[dst] = src); the 96-byte records then move in pass 4 with coalesced writes.
 __global__ void __launch_bounds__(256)
-bin_scatter_kernel(Store src, Store dst, long long n, const int *__restrict__ key,
-                   const int *__restrict__ rank, const int *__restrict__ tile_start)
+bin_source_kernel(long long n, const int *__restrict__ key, const int *__restrict__ rank,
+                  const int *__restrict__ tile_start, int *__restrict__ source)
 {
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    long long d = (long long)tile_start[key[j]] + rank[j];
+    source[tile_start[key[j]] + rank[j]] = (int)j;
+}
+
+// Pass 4: gather every record into its slot of the binned store.  Writes are perfectly
+// coalesced; reads follow `source`, which is close to the identity because the store was
+// binned a few steps ago, so they coalesce almost as well.
+__global__ void __launch_bounds__(256)
+bin_gather_kernel(Store src, Store dst, long long n, const int *__restrict__ source)
+{
+    long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n) return;
+    long long j = source[d];
 #pragma unroll
     for (int w = 0; w < kRecordWords; w++) dst.slot(w)[d] = src.slot(w)[j];
 }
@@ -765,7 +777,11 @@ inline int rebin(TiledState &T, Store src, Store dst, long long n, const Params 
     hipLaunchKernelGGL(bin_count_kernel, dim3(blocks), dim3(256), 0, stream, src, n, P, td, T.key, T.rank, T.tile_count);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, stream, T.tile_count, T.n_tiles, T.tile_start,
                        T.items, T.n_items, T.item_cap);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n, T.key, T.rank, T.tile_start);
+    // `key` is dead once `source` is built, but both are read/written in pass 3, so the
+    // straggler list (unused during a re-bin) lends its storage for `source`.
+    int *source = T.stragglers.list;
+    hipLaunchKernelGGL(bin_source_kernel, dim3(blocks), dim3(256), 0, stream, n, T.key, T.rank, T.tile_start, source);
+    hipLaunchKernelGGL(bin_gather_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n, source);
     e = hipGetLastError();
     if (e != hipSuccess) { *msg = std::string("rebin launch: ") + hipGetErrorString(e); return 1; }
     T.valid = true;
