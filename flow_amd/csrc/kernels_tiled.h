@@ -44,6 +44,9 @@ constexpr int kTiledThreads = 256;
 #ifndef FLOWMPM_G2P_WAVES
 #define FLOWMPM_G2P_WAVES 1
 #endif
+#ifndef FLOWMPM_G2P_PHASE_BARRIERS
+#define FLOWMPM_G2P_PHASE_BARRIERS 0
+#endif
 #ifndef FLOWMPM_SLAB_FENCE
 #define FLOWMPM_SLAB_FENCE 1
 #endif
@@ -613,9 +616,11 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                 B[6] = B[6] + wvx * dz; B[7] = B[7] + wvy * dz; B[8] = B[8] + wvz * dz;
                 v.x = v.x + wvx; v.y = v.y + wvy; v.z = v.z + wvz;
             }
-#if FLOWMPM_SLAB_FENCE
+#if FLOWMPM_SLAB_FENCE == 1
             // keep the compiler from hoisting all 27 arena reads (108 VGPRs) to the top
             if (INSIDE) asm volatile("" ::: "memory");
+#elif FLOWMPM_SLAB_FENCE == 2
+            if (INSIDE) __builtin_amdgcn_sched_barrier(0);
 #endif
         }
 }
@@ -653,10 +658,16 @@ g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict
         int abase;
         if (stencil_in_arena(s, A, &abase)) {
             Vec3 v = g2p_pre_forces(in.px, in.py, in.pz, P);
+#if FLOWMPM_G2P_PHASE_BARRIERS
+            __builtin_amdgcn_sched_barrier(0);     // let the noise temporaries die before the gather
+#endif
             float B[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) B[k] = 0.0f;
             g2p_gather<true>(s, grid, abase, cellf, P, v, B);
+#if FLOWMPM_G2P_PHASE_BARRIERS
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             G2POut o = g2p_finish(in, v, B, P);
 #pragma unroll
             for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
