@@ -31,7 +31,7 @@ EXPORTS = (
     "flowmpm_get_num_particles", "flowmpm_set_uniforms", "flowmpm_step", "flowmpm_run_kernel",
     "flowmpm_synchronize", "flowmpm_download_particles", "flowmpm_download_field",
     "flowmpm_get_local_grid", "flowmpm_download_grid_i32", "flowmpm_download_grid_f32",
-    "flowmpm_set_profiling", "flowmpm_get_timings", "flowmpm_reset_timings", "flowmpm_plane_ptr",
+    "flowmpm_set_profiling", "flowmpm_get_timings", "flowmpm_reset_timings", "flowmpm_plane_bytes",
     "flowmpm_plane_add_i32", "flowmpm_plane_copy_out", "flowmpm_extract_leavers",
     "flowmpm_insert_arrivals",
 )
@@ -112,7 +112,7 @@ def load():
         "flowmpm_set_profiling": ([vp, i32], ctypes.c_int),
         "flowmpm_get_timings": ([vp, ctypes.POINTER(Timings)], ctypes.c_int),
         "flowmpm_reset_timings": ([vp], ctypes.c_int),
-        "flowmpm_plane_ptr": ([vp, i32, ctypes.POINTER(vp), i64p], ctypes.c_int),
+        "flowmpm_plane_bytes": ([vp, i64p], ctypes.c_int),
         "flowmpm_plane_add_i32": ([vp, i32, vp, u32], ctypes.c_int),
         "flowmpm_plane_copy_out": ([vp, i32, vp], ctypes.c_int),
         "flowmpm_extract_leavers": ([vp, ip, i32, vp, i64, i64p], ctypes.c_int),

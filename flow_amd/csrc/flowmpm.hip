@@ -44,7 +44,9 @@ struct flowmpm_sim {
     long long uploaded = 0;      // records given to upload (single GPU)
     mpm::Store store{};
     mpm::Store store_alt{};      // tiled: re-binning target
-    int4 *cell = nullptr;
+    int4 *cell = nullptr;        // momentum words (word 3 unused on the device)
+    int *mass_i = nullptr;       // mass words, one per cell
+    mpm::FixedGrid fixed() const { return mpm::FixedGrid{reinterpret_cast<int *>(cell), mass_i}; }
     float4 *cellf = nullptr;
     long long local_cells = 0;
     std::vector<float> shadow;   // host copy of records beyond `live` (single GPU)
@@ -169,7 +171,7 @@ int stage_clear_grid(flowmpm_sim *s)
     if (rc) return rc;
     unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
     hipLaunchKernelGGL(mpm::clear_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, s->cell,
-                       s->cellf, s->local_cells);
+                       s->mass_i, s->cellf, s->local_cells);
     if ((rc = launch_check(s, "clear_grid"))) return rc;
     return timing_end(s, t);
 }
@@ -185,11 +187,11 @@ int stage_p2g1(flowmpm_sim *s)
     if ((rc = timing_begin(s, FLOWMPM_KERNEL_P2G1, &t))) return rc;
     if (s->live > 0) {
         if (is_tiled(s)) {
-            if ((rc = mpm::launch_p2g1_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream)))
+            if ((rc = mpm::launch_p2g1_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream)))
                 return fail(s, FLOWMPM_ERR_HIP, "p2g1_tiled launch failed");
         } else {
             hipLaunchKernelGGL(mpm::p2g1_scatter_kernel, dim3(blocks_for(s->live, 256)), dim3(256), 0,
-                               s->stream, s->store, s->live, reinterpret_cast<int *>(s->cell), s->params);
+                               s->stream, s->store, s->live, s->fixed(), s->params);
         }
         if ((rc = launch_check(s, "p2g1"))) return rc;
     }
@@ -204,11 +206,11 @@ int stage_p2g2(flowmpm_sim *s)
     if ((rc = timing_begin(s, FLOWMPM_KERNEL_P2G2, &t))) return rc;
     if (s->live > 0) {
         if (is_tiled(s)) {
-            if ((rc = mpm::launch_p2g2_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream)))
+            if ((rc = mpm::launch_p2g2_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream)))
                 return fail(s, FLOWMPM_ERR_HIP, "p2g2_tiled launch failed");
         } else {
             hipLaunchKernelGGL(mpm::p2g2_scatter_kernel, dim3(blocks_for(s->live, 256)), dim3(256), 0,
-                               s->stream, s->store, s->live, reinterpret_cast<int *>(s->cell), s->params);
+                               s->stream, s->store, s->live, s->fixed(), s->params);
         }
         if ((rc = launch_check(s, "p2g2"))) return rc;
     }
@@ -226,8 +228,8 @@ int stage_p2g_pass(flowmpm_sim *s, bool momentum)
     size_t t;
     if ((rc = timing_begin(s, momentum ? FLOWMPM_KERNEL_P2G2 : FLOWMPM_KERNEL_P2G1, &t))) return rc;
     if (s->live > 0) {
-        rc = momentum ? mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream)
-                      : mpm::launch_p2g_mass_tiled(s->tiled, s->store, s->live, s->cell, s->params, s->stream);
+        rc = momentum ? mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream)
+                      : mpm::launch_p2g_mass_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream);
         if (rc) return fail(s, FLOWMPM_ERR_HIP, "p2g pass: could not reset the straggler counter");
         if ((rc = launch_check(s, momentum ? "p2g_momentum" : "p2g_mass"))) return rc;
     }
@@ -241,7 +243,7 @@ int stage_update_grid(flowmpm_sim *s)
     if (rc) return rc;
     unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
     hipLaunchKernelGGL(mpm::update_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, s->cell,
-                       s->cellf, s->local_cells, s->params);
+                       s->mass_i, s->cellf, s->local_cells, s->params);
     if ((rc = launch_check(s, "update_grid"))) return rc;
     return timing_end(s, t);
 }
@@ -419,7 +421,9 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         s->local_cells = (long long)s->params.local_nx * c.grid_y * c.grid_z;
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->cell), (size_t)s->local_cells * sizeof(int4)));
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->cellf), (size_t)s->local_cells * sizeof(float4)));
+        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->mass_i), (size_t)s->local_cells * sizeof(int)));
         HIP_TRY(s, hipMemsetAsync(s->cell, 0, (size_t)s->local_cells * sizeof(int4), s->stream));
+        HIP_TRY(s, hipMemsetAsync(s->mass_i, 0, (size_t)s->local_cells * sizeof(int), s->stream));
         HIP_TRY(s, hipMemsetAsync(s->cellf, 0, (size_t)s->local_cells * sizeof(float4), s->stream));
         int r = alloc_store(s, &s->store);
         if (r) return r;
@@ -455,6 +459,7 @@ int flowmpm_destroy(flowmpm_sim *s)
     if (s->store.base) (void)hipFree(s->store.base);
     if (s->store_alt.base) (void)hipFree(s->store_alt.base);
     if (s->cell) (void)hipFree(s->cell);
+    if (s->mass_i) (void)hipFree(s->mass_i);
     if (s->cellf) (void)hipFree(s->cellf);
     if (s->mig_counters) (void)hipFree(s->mig_counters);
     if (s->mig_lists) (void)hipFree(s->mig_lists);
@@ -636,8 +641,17 @@ int flowmpm_download_grid_i32(flowmpm_sim *s, int32_t *out, int64_t capacity_cel
 {
     CHECK_SIM(s);
     if (!out || capacity_cells < s->local_cells) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
-    HIP_TRY(s, hipMemcpyAsync(out, s->cell, (size_t)s->local_cells * sizeof(int4), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    // The device keeps the mass words apart; hosts get the reference's {x, y, z, mass} records.
+    int4 *tmp = nullptr;
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)s->local_cells * sizeof(int4)));
+    hipLaunchKernelGGL(mpm::assemble_cells_kernel, dim3(blocks_for(s->local_cells, 256)), dim3(256), 0, s->stream,
+                       s->cell, s->mass_i, tmp, s->local_cells);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, tmp, (size_t)s->local_cells * sizeof(int4), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("download_grid_i32: ") + hipGetErrorString(e));
     return FLOWMPM_OK;
 }
 
@@ -695,13 +709,10 @@ static int plane_index(flowmpm_sim *s, int32_t plane, long long *first_cell)
     return FLOWMPM_OK;
 }
 
-int flowmpm_plane_ptr(flowmpm_sim *s, int32_t plane, void **dev_ptr, int64_t *bytes)
+int flowmpm_plane_bytes(flowmpm_sim *s, int64_t *bytes)
 {
     if (!s) return fail(nullptr, FLOWMPM_ERR_INVALID, "null handle");
-    long long first;
-    int rc = plane_index(s, plane, &first);
-    if (rc) return rc;
-    if (dev_ptr) *dev_ptr = s->cell + first;
+    if (!s->slab) return fail(s, FLOWMPM_ERR_INVALID, "not a slab handle");
     if (bytes) *bytes = (int64_t)s->cfg.grid_y * s->cfg.grid_z * (int64_t)sizeof(int4);
     return FLOWMPM_OK;
 }
@@ -715,7 +726,8 @@ int flowmpm_plane_add_i32(flowmpm_sim *s, int32_t plane, const void *dev_src, ui
     if (!dev_src) return fail(s, FLOWMPM_ERR_INVALID, "null source");
     long long cells = (long long)s->cfg.grid_y * s->cfg.grid_z;
     hipLaunchKernelGGL(mpm::plane_add_kernel, dim3(blocks_for(cells, 256)), dim3(256), 0, s->stream,
-                       s->cell + first, reinterpret_cast<const int4 *>(dev_src), cells, comp_mask & 0xFu);
+                       s->cell + first, s->mass_i + first, reinterpret_cast<const int4 *>(dev_src), cells,
+                       comp_mask & 0xFu);
     return launch_check(s, "plane_add");
 }
 
@@ -726,9 +738,10 @@ int flowmpm_plane_copy_out(flowmpm_sim *s, int32_t plane, void *dev_dst)
     int rc = plane_index(s, plane, &first);
     if (rc) return rc;
     if (!dev_dst) return fail(s, FLOWMPM_ERR_INVALID, "null destination");
-    size_t bytes = (size_t)s->cfg.grid_y * s->cfg.grid_z * sizeof(int4);
-    HIP_TRY(s, hipMemcpyAsync(dev_dst, s->cell + first, bytes, hipMemcpyDeviceToDevice, s->stream));
-    return FLOWMPM_OK;
+    long long cells = (long long)s->cfg.grid_y * s->cfg.grid_z;
+    hipLaunchKernelGGL(mpm::assemble_cells_kernel, dim3(blocks_for(cells, 256)), dim3(256), 0, s->stream,
+                       s->cell + first, s->mass_i + first, reinterpret_cast<int4 *>(dev_dst), cells);
+    return launch_check(s, "plane_copy_out");
 }
 
 int flowmpm_extract_leavers(flowmpm_sim *s, const int32_t *plane_starts, int32_t n_ranks, void *dev_out,

@@ -16,6 +16,17 @@ struct Store {
     __device__ __host__ __forceinline__ int *ids() const { return reinterpret_cast<int *>(slot(kId)); }
 };
 
+// The fixed-point grid (cellBuffer, SIM:131-138) as the device holds it: momentum in 16-byte
+// records {x, y, z, unused} and the mass words in an array of their own, so that the mass
+// pass of the tiled algorithm flushes contiguous 4-byte atomics (a 64-byte memory-side atomic
+// request then carries 16 cells instead of 4) and the density gather reads 4 bytes per cell.
+// Hosts always see the reference's {x, y, z, mass} records: downloads and halo planes are
+// assembled by kernels below.
+struct FixedGrid {
+    int *cell;      // 4 ints per cell; word 3 is not used on the device
+    int *mass;      // 1 int per cell
+};
+
 // Local linear cell index (SIM:286-290) or -1 when the cell is outside the planes
 // this handle holds (only reachable from positions the host refused to upload).
 __device__ __forceinline__ long long local_cell(int cx, int cy, int cz, const Params &P)
@@ -29,18 +40,19 @@ __device__ __forceinline__ long long local_cell(int cx, int cy, int cz, const Pa
 
 // SIM:262-277.  One thread clears one cell of both grids with two 16-byte stores.
 __global__ void __launch_bounds__(256)
-clear_grid_kernel(int4 *__restrict__ cell, float4 *__restrict__ cellf, long long cells)
+clear_grid_kernel(int4 *__restrict__ cell, int *__restrict__ mass, float4 *__restrict__ cellf, long long cells)
 {
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
         cell[i] = make_int4(0, 0, 0, 0);
+        mass[i] = 0;
         cellf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 
 // SIM:295-333.
 __global__ void __launch_bounds__(256)
-p2g1_scatter_kernel(Store st, long long n, int *__restrict__ cell, Params P)
+p2g1_scatter_kernel(Store st, long long n, FixedGrid g, Params P)
 {
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -64,11 +76,11 @@ p2g1_scatter_kernel(Store st, long long n, int *__restrict__ cell, Params P)
                 float qz = (C[2] * dx + C[5] * dy) + C[8] * dz;
                 long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                 if (c < 0) continue;
-                int *p = cell + 4 * c;
+                int *p = g.cell + 4 * c;
                 atomicAdd(p + 0, encode_fixed(weight * (vx + qx)));
                 atomicAdd(p + 1, encode_fixed(weight * (vy + qy)));
                 atomicAdd(p + 2, encode_fixed(weight * (vz + qz)));
-                atomicAdd(p + 3, encode_fixed(weight));
+                atomicAdd(g.mass + c, encode_fixed(weight));
             }
         }
     }
@@ -76,7 +88,7 @@ p2g1_scatter_kernel(Store st, long long n, int *__restrict__ cell, Params P)
 
 // SIM:336-392.
 __global__ void __launch_bounds__(256)
-p2g2_scatter_kernel(Store st, long long n, int *__restrict__ cell, Params P)
+p2g2_scatter_kernel(Store st, long long n, FixedGrid g, Params P)
 {
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -96,7 +108,7 @@ p2g2_scatter_kernel(Store st, long long n, int *__restrict__ cell, Params P)
             for (int gz = 0; gz < 3; gz++) {
                 float weight = wxy * s.wz[gz];
                 long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
-                int m = (c >= 0) ? cell[4 * c + 3] : 0;
+                int m = (c >= 0) ? g.mass[c] : 0;
                 density = density + decode_fixed(m) * weight;
             }
         }
@@ -120,7 +132,7 @@ p2g2_scatter_kernel(Store st, long long n, int *__restrict__ cell, Params P)
                 float mz = (a02 * dx + a12 * dy) + a22 * dz;
                 long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                 if (c < 0) continue;
-                int *p = cell + 4 * c;
+                int *p = g.cell + 4 * c;
                 atomicAdd(p + 0, encode_fixed(mx));
                 atomicAdd(p + 1, encode_fixed(my));
                 atomicAdd(p + 2, encode_fixed(mz));
@@ -130,15 +142,15 @@ p2g2_scatter_kernel(Store st, long long n, int *__restrict__ cell, Params P)
 
 // SIM:395-429.  Cells with mass <= 0 keep what clearGrid wrote (zeros).
 __global__ void __launch_bounds__(256)
-update_grid_kernel(const int4 *__restrict__ cell, float4 *__restrict__ cellf, long long cells,
-                   Params P)
+update_grid_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass_i,
+                   float4 *__restrict__ cellf, long long cells, Params P)
 {
     long long stride = (long long)gridDim.x * blockDim.x;
     const int plane = P.gy * P.gz;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
-        int4 c = cell[i];
-        float mass = decode_fixed(c.w);
+        float mass = decode_fixed(mass_i[i]);
         if (!(mass > 0.0f)) continue;
+        int4 c = cell[i];
         float vx = decode_fixed(c.x) / mass;
         float vy = decode_fixed(c.y) / mass;
         float vz = decode_fixed(c.z) / mass;
@@ -255,17 +267,33 @@ gather_field_kernel(Store st, long long count, int first_slot, int width, float 
 
 // Halo merge of the slab decomposition: dst.comp += src.comp (wrapping i32).
 __global__ void __launch_bounds__(256)
-plane_add_kernel(int4 *__restrict__ dst, const int4 *__restrict__ src, long long cells,
-                 unsigned mask)
+plane_add_kernel(int4 *__restrict__ dst, int *__restrict__ dst_mass, const int4 *__restrict__ src,
+                 long long cells, unsigned mask)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cells) return;
-    int4 d = dst[i], s = src[i];
-    if (mask & 1u) d.x = (int)((unsigned)d.x + (unsigned)s.x);
-    if (mask & 2u) d.y = (int)((unsigned)d.y + (unsigned)s.y);
-    if (mask & 4u) d.z = (int)((unsigned)d.z + (unsigned)s.z);
-    if (mask & 8u) d.w = (int)((unsigned)d.w + (unsigned)s.w);
-    dst[i] = d;
+    int4 s = src[i];
+    if (mask & 7u) {
+        int4 d = dst[i];
+        if (mask & 1u) d.x = (int)((unsigned)d.x + (unsigned)s.x);
+        if (mask & 2u) d.y = (int)((unsigned)d.y + (unsigned)s.y);
+        if (mask & 4u) d.z = (int)((unsigned)d.z + (unsigned)s.z);
+        dst[i] = d;
+    }
+    if (mask & 8u) dst_mass[i] = (int)((unsigned)dst_mass[i] + (unsigned)s.w);
+}
+
+// The reference's cell records {x, y, z, mass} of `cells` consecutive cells, assembled from
+// the device layout (downloads, halo-plane send staging).
+__global__ void __launch_bounds__(256)
+assemble_cells_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass, int4 *__restrict__ out,
+                      long long cells)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    int4 c = cell[i];
+    c.w = mass[i];
+    out[i] = c;
 }
 
 }  // namespace mpm

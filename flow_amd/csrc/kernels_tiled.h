@@ -218,7 +218,7 @@ __device__ __forceinline__ void add_straggler(const Stragglers &sg, int j)
 // in runs of contiguous 16-byte cell records.
 template <int NCOMP>
 __device__ __forceinline__ void flush_arena(const int *lds, const Arena &A, const Params &P,
-                                            int *__restrict__ cell)
+                                            FixedGrid g)
 {
     for (int f = threadIdx.x; f < kArenaCells * 4; f += kTiledThreads) {
         int comp = f & 3, a = f >> 2;
@@ -226,7 +226,9 @@ __device__ __forceinline__ void flush_arena(const int *lds, const Arena &A, cons
         int v = lds[comp * kArenaPad + a];
         if (v == 0) continue;
         long long c = arena_cell_to_grid(a, A, P);
-        if (c >= 0) atomicAdd(cell + 4 * c + comp, v);
+        if (c < 0) continue;
+        if (comp == 3) atomicAdd(g.mass + c, v);
+        else atomicAdd(g.cell + 4 * c + comp, v);
     }
 }
 
@@ -237,7 +239,7 @@ __device__ __forceinline__ void flush_arena(const int *lds, const Arena &A, cons
 // the last re-bin) it goes straight to the global grid.
 template <bool INSIDE>
 __device__ __forceinline__ void p2g1_particle(const Stencil &s, float vx, float vy, float vz, const float C[9],
-                                              int *lds, int abase, int *__restrict__ cell, const Params &P)
+                                              int *lds, int abase, FixedGrid g, const Params &P)
 {
 #pragma unroll
     for (int gx = 0; gx < 3; gx++) {
@@ -264,10 +266,10 @@ __device__ __forceinline__ void p2g1_particle(const Stencil &s, float vx, float 
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     if (c >= 0) {
-                        atomicAdd(cell + 4 * c + 0, ex);
-                        atomicAdd(cell + 4 * c + 1, ey);
-                        atomicAdd(cell + 4 * c + 2, ez);
-                        atomicAdd(cell + 4 * c + 3, em);
+                        atomicAdd(g.cell + 4 * c + 0, ex);
+                        atomicAdd(g.cell + 4 * c + 1, ey);
+                        atomicAdd(g.cell + 4 * c + 2, ez);
+                        atomicAdd(g.mass + c, em);
                     }
                 }
             }
@@ -285,7 +287,7 @@ __device__ __forceinline__ bool stencil_in_arena(const Stencil &s, const Arena &
 
 __global__ void __launch_bounds__(kTiledThreads)
 p2g1_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                  TileDims td, int *__restrict__ cell, Params P, Stragglers sg)
+                  TileDims td, FixedGrid g, Params P, Stragglers sg)
 {
     if ((int)blockIdx.x >= *n_items) return;
     __shared__ int lds[4 * kArenaPad];
@@ -303,19 +305,19 @@ p2g1_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restric
         Stencil s = make_stencil(px, py, pz);
         int abase;
         if (stencil_in_arena(s, A, &abase))
-            p2g1_particle<true>(s, vx, vy, vz, C, lds, abase, cell, P);
+            p2g1_particle<true>(s, vx, vy, vz, C, lds, abase, g, P);
         else
             add_straggler(sg, j);
     }
     __syncthreads();
-    flush_arena<4>(lds, A, P, cell);
+    flush_arena<4>(lds, A, P, g);
 }
 
 // ---- p2g2 (SIM:336-392) ------------------------------------------------------------
 
 template <bool INSIDE>
 __device__ __forceinline__ void p2g2_particle(const Stencil &s, const float C[9], float *dens_slot, int *lds,
-                                              const float *mass_f, int abase, int *__restrict__ cell,
+                                              const float *mass_f, int abase, FixedGrid g,
                                               const Params &P)
 {
     float density = 0.0f;
@@ -332,7 +334,7 @@ __device__ __forceinline__ void p2g2_particle(const Stencil &s, const float C[9]
                     m = mass_f[abase + arena_index(gx, gy, gz)];
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
-                    m = decode_fixed((c >= 0) ? cell[4 * c + 3] : 0);
+                    m = decode_fixed((c >= 0) ? g.mass[c] : 0);
                 }
                 density = density + m * weight;
             }
@@ -361,9 +363,9 @@ __device__ __forceinline__ void p2g2_particle(const Stencil &s, const float C[9]
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     if (c >= 0) {
-                        atomicAdd(cell + 4 * c + 0, ex);
-                        atomicAdd(cell + 4 * c + 1, ey);
-                        atomicAdd(cell + 4 * c + 2, ez);
+                        atomicAdd(g.cell + 4 * c + 0, ex);
+                        atomicAdd(g.cell + 4 * c + 1, ey);
+                        atomicAdd(g.cell + 4 * c + 2, ez);
                     }
                 }
             }
@@ -372,7 +374,7 @@ __device__ __forceinline__ void p2g2_particle(const Stencil &s, const float C[9]
 
 __global__ void __launch_bounds__(kTiledThreads)
 p2g2_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                  TileDims td, int *__restrict__ cell, Params P, Stragglers sg)
+                  TileDims td, FixedGrid g, Params P, Stragglers sg)
 {
     if ((int)blockIdx.x >= *n_items) return;
     __shared__ int lds[3 * kArenaPad];
@@ -382,7 +384,7 @@ p2g2_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restric
     for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
         long long c = arena_cell_to_grid(a, A, P);
-        int m = (c >= 0) ? cell[4 * c + 3] : 0;
+        int m = (c >= 0) ? g.mass[c] : 0;
         mass_f[a] = decode_fixed(m);
     }
     __syncthreads();
@@ -396,12 +398,12 @@ p2g2_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restric
         Stencil s = make_stencil(px, py, pz);
         int abase;
         if (stencil_in_arena(s, A, &abase))
-            p2g2_particle<true>(s, C, dens + j, lds, mass_f, abase, cell, P);
+            p2g2_particle<true>(s, C, dens + j, lds, mass_f, abase, g, P);
         else
             add_straggler(sg, j);
     }
     __syncthreads();
-    flush_arena<3>(lds, A, P, cell);
+    flush_arena<3>(lds, A, P, g);
 }
 
 // ---- fused p2g: mass pass + momentum pass --------------------------------------------
@@ -420,7 +422,7 @@ p2g2_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restric
 __device__ __forceinline__ int add_wrap(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 
 template <bool INSIDE>
-__device__ __forceinline__ void p2g_mass_particle(const Stencil &s, int *lds, int abase, int *__restrict__ cell,
+__device__ __forceinline__ void p2g_mass_particle(const Stencil &s, int *lds, int abase, FixedGrid g,
                                                   const Params &P)
 {
 #pragma unroll
@@ -435,7 +437,7 @@ __device__ __forceinline__ void p2g_mass_particle(const Stencil &s, int *lds, in
                     atomicAdd(&lds[abase + arena_index(gx, gy, gz)], em);
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
-                    if (c >= 0) atomicAdd(cell + 4 * c + 3, em);
+                    if (c >= 0) atomicAdd(g.mass + c, em);
                 }
             }
         }
@@ -443,7 +445,7 @@ __device__ __forceinline__ void p2g_mass_particle(const Stencil &s, int *lds, in
 
 __global__ void __launch_bounds__(kTiledThreads)
 p2g_mass_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                      TileDims td, int *__restrict__ cell, Params P, Stragglers sg)
+                      TileDims td, FixedGrid g, Params P, Stragglers sg)
 {
     if ((int)blockIdx.x >= *n_items) return;
     __shared__ int lds[kArenaCells];
@@ -455,7 +457,7 @@ p2g_mass_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__res
         Stencil s = make_stencil(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j]);
         int abase;
         if (stencil_in_arena(s, A, &abase))
-            p2g_mass_particle<true>(s, lds, abase, cell, P);
+            p2g_mass_particle<true>(s, lds, abase, g, P);
         else
             add_straggler(sg, j);
     }
@@ -464,14 +466,14 @@ p2g_mass_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__res
         int v = lds[a];
         if (v == 0) continue;
         long long c = arena_cell_to_grid(a, A, P);
-        if (c >= 0) atomicAdd(cell + 4 * c + 3, v);
+        if (c >= 0) atomicAdd(g.mass + c, v);
     }
 }
 
 template <bool INSIDE>
 __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx, float vy, float vz,
                                                       const float C[9], float *dens_slot, int *lds,
-                                                      const float *mass_f, int abase, int *__restrict__ cell,
+                                                      const float *mass_f, int abase, FixedGrid g,
                                                       const Params &P)
 {
     float density = 0.0f;
@@ -488,7 +490,7 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
                     m = mass_f[abase + arena_index(gx, gy, gz)];
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
-                    m = decode_fixed((c >= 0) ? cell[4 * c + 3] : 0);
+                    m = decode_fixed((c >= 0) ? g.mass[c] : 0);
                 }
                 density = density + m * weight;
             }
@@ -525,9 +527,9 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     if (c >= 0) {
-                        atomicAdd(cell + 4 * c + 0, ex);
-                        atomicAdd(cell + 4 * c + 1, ey);
-                        atomicAdd(cell + 4 * c + 2, ez);
+                        atomicAdd(g.cell + 4 * c + 0, ex);
+                        atomicAdd(g.cell + 4 * c + 1, ey);
+                        atomicAdd(g.cell + 4 * c + 2, ez);
                     }
                 }
             }
@@ -536,7 +538,7 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
 
 __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_P2G_WAVES)
 p2g_momentum_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                          TileDims td, int *__restrict__ cell, Params P, Stragglers sg)
+                          TileDims td, FixedGrid g, Params P, Stragglers sg)
 {
     if ((int)blockIdx.x >= *n_items) return;
     __shared__ int lds[3 * kArenaPad];
@@ -546,7 +548,7 @@ p2g_momentum_tiled_kernel(Store st, const int4 *__restrict__ items, const int *_
     for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
         long long c = arena_cell_to_grid(a, A, P);
-        mass_f[a] = decode_fixed((c >= 0) ? cell[4 * c + 3] : 0);
+        mass_f[a] = decode_fixed((c >= 0) ? g.mass[c] : 0);
     }
     __syncthreads();
     float *dens = st.slot(kDensity);
@@ -570,7 +572,7 @@ p2g_momentum_tiled_kernel(Store st, const int4 *__restrict__ items, const int *_
         Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
         int abase;
         if (stencil_in_arena(s, A, &abase))
-            p2g_momentum_particle<true>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + j, lds, mass_f, abase, cell, P);
+            p2g_momentum_particle<true>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + j, lds, mass_f, abase, g, P);
         else
             add_straggler(sg, j);
 #if FLOWMPM_PREFETCH_P2G
@@ -585,7 +587,7 @@ p2g_momentum_tiled_kernel(Store st, const int4 *__restrict__ items, const int *_
         j = jn;
     }
     __syncthreads();
-    flush_arena<3>(lds, A, P, cell);
+    flush_arena<3>(lds, A, P, g);
 }
 
 // ---- g2p (SIM:431-1536, chaos path) -----------------------------------------------
@@ -691,7 +693,7 @@ g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict
 // (the reference's own access pattern).  PASS: 0 p2g1, 1 p2g2, 2 mass pass, 3 momentum pass.
 template <int PASS>
 __global__ void __launch_bounds__(256)
-straggler_p2g_kernel(Store st, Stragglers sg, int *__restrict__ cell, Params P)
+straggler_p2g_kernel(Store st, Stragglers sg, FixedGrid g, Params P)
 {
     const int count = *sg.count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
@@ -700,12 +702,12 @@ straggler_p2g_kernel(Store st, Stragglers sg, int *__restrict__ cell, Params P)
 #pragma unroll
         for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
         Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
-        if (PASS == 0) p2g1_particle<false>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, nullptr, 0, cell, P);
-        if (PASS == 1) p2g2_particle<false>(s, in + kC00, st.slot(kDensity) + j, nullptr, nullptr, 0, cell, P);
-        if (PASS == 2) p2g_mass_particle<false>(s, nullptr, 0, cell, P);
+        if (PASS == 0) p2g1_particle<false>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, nullptr, 0, g, P);
+        if (PASS == 1) p2g2_particle<false>(s, in + kC00, st.slot(kDensity) + j, nullptr, nullptr, 0, g, P);
+        if (PASS == 2) p2g_mass_particle<false>(s, nullptr, 0, g, P);
         if (PASS == 3)
             p2g_momentum_particle<false>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, st.slot(kDensity) + j,
-                                         nullptr, nullptr, 0, cell, P);
+                                         nullptr, nullptr, 0, g, P);
     }
 }
 
@@ -820,25 +822,25 @@ constexpr int kStragglerBlocks = 128;
         return 0;                                                                                           \
     } while (0)
 
-inline int launch_p2g1_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P, hipStream_t stream)
+inline int launch_p2g1_tiled(TiledState &T, Store st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
 {
-    FLOWMPM_TILED_STAGE(p2g1_tiled_kernel, straggler_p2g_kernel<0>, reinterpret_cast<int *>(cell));
+    FLOWMPM_TILED_STAGE(p2g1_tiled_kernel, straggler_p2g_kernel<0>, g);
 }
 
-inline int launch_p2g2_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P, hipStream_t stream)
+inline int launch_p2g2_tiled(TiledState &T, Store st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
 {
-    FLOWMPM_TILED_STAGE(p2g2_tiled_kernel, straggler_p2g_kernel<1>, reinterpret_cast<int *>(cell));
+    FLOWMPM_TILED_STAGE(p2g2_tiled_kernel, straggler_p2g_kernel<1>, g);
 }
 
-inline int launch_p2g_mass_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P, hipStream_t stream)
+inline int launch_p2g_mass_tiled(TiledState &T, Store st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
 {
-    FLOWMPM_TILED_STAGE(p2g_mass_tiled_kernel, straggler_p2g_kernel<2>, reinterpret_cast<int *>(cell));
+    FLOWMPM_TILED_STAGE(p2g_mass_tiled_kernel, straggler_p2g_kernel<2>, g);
 }
 
-inline int launch_p2g_momentum_tiled(TiledState &T, Store st, long long n, int4 *cell, const Params &P,
+inline int launch_p2g_momentum_tiled(TiledState &T, Store st, long long n, FixedGrid g, const Params &P,
                                      hipStream_t stream)
 {
-    FLOWMPM_TILED_STAGE(p2g_momentum_tiled_kernel, straggler_p2g_kernel<3>, reinterpret_cast<int *>(cell));
+    FLOWMPM_TILED_STAGE(p2g_momentum_tiled_kernel, straggler_p2g_kernel<3>, g);
 }
 
 inline int launch_g2p_tiled(TiledState &T, Store st, long long n, const float4 *cellf, const Params &P,

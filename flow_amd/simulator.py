@@ -155,10 +155,10 @@ class Handle:
         return {names[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(len(names))}
 
     # ---- slab decomposition ----
-    def plane_ptr(self, plane):
-        p, nbytes = ctypes.c_void_p(), ctypes.c_int64()
-        self._chk(self.L.flowmpm_plane_ptr(self._h, int(plane), ctypes.byref(p), ctypes.byref(nbytes)))
-        return p.value, nbytes.value
+    def plane_bytes(self):
+        nbytes = ctypes.c_int64()
+        self._chk(self.L.flowmpm_plane_bytes(self._h, ctypes.byref(nbytes)))
+        return nbytes.value
 
     def plane_add_i32(self, plane, dev_src, comp_mask):
         self._chk(self.L.flowmpm_plane_add_i32(self._h, int(plane), ctypes.c_void_p(dev_src), int(comp_mask)))

@@ -175,16 +175,17 @@ int flowmpm_get_timings(flowmpm_sim *sim, flowmpm_timings *out);
 int flowmpm_reset_timings(flowmpm_sim *sim);
 
 /* ---- Slab decomposition (no reference counterpart: the reference is single-GPU).
- * The caller owns the transport (RCCL through torch.distributed); these expose the
- * device-side pieces.  Device pointers returned here stay valid until destroy. ---- */
+ * The caller owns the transport (RCCL through torch.distributed) and its device buffers;
+ * these are the device-side pieces. ---- */
 
-/* Device address and byte size of one boundary plane of the i32 grid. */
-int flowmpm_plane_ptr(flowmpm_sim *sim, int32_t plane, void **dev_ptr, int64_t *bytes);
+/* Byte size of one boundary plane as exchanged: grid_y * grid_z records {x, y, z, mass}. */
+int flowmpm_plane_bytes(flowmpm_sim *sim, int64_t *bytes);
 /* grid[plane].comp += src.comp for the components in `comp_mask`, as wrapping i32 adds;
- * `dev_src` is a device buffer holding one plane in the grid's own layout. */
+ * `dev_src` is a device buffer holding one plane of {x, y, z, mass} records (SIM:131-138). */
 int flowmpm_plane_add_i32(flowmpm_sim *sim, int32_t plane, const void *dev_src,
                           uint32_t comp_mask);
-/* Copies one boundary plane into a caller's device buffer (send staging). */
+/* Writes one boundary plane as {x, y, z, mass} records into a caller's device buffer (send
+ * staging). */
 int flowmpm_plane_copy_out(flowmpm_sim *sim, int32_t plane, void *dev_dst);
 /* Splits the resident particles after g2p: those whose floor(position.x) left
  * [slab_x0, slab_x0 + slab_nx) are removed from the handle and written as packed
