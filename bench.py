@@ -85,6 +85,17 @@ def cpu_baseline(rec, n, grid, uniforms, steps):
                       % (steps, n, grid[0], grid[1], grid[2])}
 
 
+def measured_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE doubled as gfx950 needs for coalesced reads, plus
+    WRITE_SIZE, each from its own --pmc run), or None when that workload was not profiled."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    return table.get(workload, {}).get(kernel)
+
+
 def roofline_of(timings, n, cells):
     """Roofline entry of the kernel with the largest share of the step.  The tiled path runs
     p2g1 + p2g2 as a mass pass and a summed-momentum pass, which moves work (and bytes) from the
@@ -128,17 +139,35 @@ def run_single(args):
     rec = make_particles(args.scene, n, grid, seed)
     h.upload_particles(rec)
     h.set_uniforms(**uniforms)
-    h.step(args.warmup, 0.0)
+
+    def advance(first, count):
+        """`count` steps.  The dam-break configuration drives a scripted mouse ray: a ray along +z
+        through the centre of the column whose hit point swings sinusoidally, which changes the
+        mouse-force uniform every step (mlsMpmSimulator.js:2530-2534); the other scenes keep
+        their uniforms and enqueue all steps in one call."""
+        if args.scene != "dam_break":
+            h.step(count, 0.0)
+            return
+        for k in range(first, first + count):
+            swing = 8.0 * np.sin(0.2 * np.array([k - 2, k], dtype=np.float64))
+            h.set_uniforms(**dict(uniforms, cursor_interaction=1, mouse_ray_direction=(0.0, 0.0, 1.0),
+                                  mouse_ray_origin=(0.125 * grid[0], 0.5 * grid[1], 0.0),
+                                  mouse_force=((swing[1] - swing[0]) / 3.0, 0.0, 0.0)))
+            h.step(1, 0.0)
+
+    advance(0, args.warmup)
     h.synchronize()
     h.set_profiling(True)
     h.reset_timings()
     t0 = time.perf_counter()
-    h.step(args.steps, 0.0)
+    advance(args.warmup, args.steps)
     h.synchronize()
     elapsed = time.perf_counter() - t0
     timings = h.timings()
     h.close()
     roof, per_kernel = roofline_of(timings, n, cells)
+    workload_key = "%s_%d_%dx%dx%d" % (args.scene, n, grid[0], grid[1], grid[2])
+    roof["traffic"] = measured_traffic(roof["kernel"], workload_key)
     rebin = timings["rebin"]
     step_bytes = 212 * n + 112 * cells
     line = {
@@ -149,7 +178,8 @@ def run_single(args):
         "config": {"workload": "16M particles, 256^3 grid, single MI355X" if (args.particles_log2 == 24 and not args.grid)
                    else "%d particles, grid %dx%dx%d, single MI355X" % (n, grid[0], grid[1], grid[2]),
                    "scene": args.scene, "particles": n, "grid": list(grid), "algorithm": args.algorithm,
-                   "rebin_interval": args.rebin_interval, "dt": 0.1, "noise": 0.0, "cursor_interaction": 0},
+                   "rebin_interval": args.rebin_interval, "dt": 0.1, "noise": 0.0,
+                   "cursor_interaction": 1 if args.scene == "dam_break" else 0},
         "roofline": roof,
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes,
                           "achieved_GBs": round(step_bytes / (elapsed / args.steps) / 1e9, 1),

@@ -353,3 +353,63 @@ def test_simulator_class_follows_the_reference_frame_loop(oracle_binding):
     assert_bits_equal(got, want, "simulator records after 3 frames")
     assert_bits_equal(sim.getPositions(), want[:live, 0:3], "getPositions")
     assert_bits_equal(sim.getDensities()[:, 0], want[:live, 3], "getDensities")
+
+
+def test_default_scene_100_steps_with_state_dumps(oracle_binding):
+    """Benchmark configuration 1: the reference's default scene (81,920 live of 262,144 allocated
+    particles, 128x64x64, conf defaults, dt = 0.1, clock = step/60), 100 steps, state compared at
+    steps 1 and 100 -- grid and every particle record bit for bit."""
+    grid, total, live = (128, 64, 64), 262144, 81920
+    uni = dict(dt=0.1, stiffness=3.0, rest_density=2.5, dynamic_viscosity=0.1, noise=1.0, time=0.0)
+    rec = reference_scene(total, grid, seed=0xF10E5EED)
+    h = _handle(grid, rec, _lib.ALGO_TILED, uniforms=uni, rebin_interval=8)
+    h.set_num_particles(live)
+    orc = oracle_binding.Oracle(grid, threads=8)
+    want = rec.copy()
+    u = oracle_binding.make_uniforms(grid, live, **uni)
+    done = 0
+    for checkpoint in (1, 100):
+        h.set_uniforms(**dict(uni, time=done / 60))
+        h.step(checkpoint - done, 1 / 60)
+        u.time = done / 60
+        orc.run(want, u, checkpoint - done, 1 / 60)
+        done = checkpoint
+        assert np.array_equal(h.download_grid_i32(), orc.cell), "fixed-point grid at step %d" % checkpoint
+        assert_bits_equal(h.download_grid_f32(), orc.cellf, "float grid at step %d" % checkpoint)
+        assert_bits_equal(h.download_particles(), want, "particle records at step %d" % checkpoint)
+    h.close()
+
+
+def test_long_run_conservation_tracking():
+    """2,000 steps at 2^18 particles: what the step conserves is tracked every 100 steps.
+    Fixed-point grid mass stays N*1e7 minus at most 27 truncation units per particle (each of
+    the 27 weights loses < 1 unit; they sum to 1 within a few ulp), the particle count and the
+    particle masses never change, positions stay inside the clamp box, nothing becomes NaN, and
+    the grid momentum of a step equals the sum of its per-cell velocity x mass read-back."""
+    grid, n = (64, 64, 64), 1 << 18
+    rec = reference_scene(n, grid, seed=77)
+    uni = dict(DEFAULT_UNIFORMS, rest_density=n / (0.268 * 64 ** 3))
+    h = _handle(grid, rec, _lib.ALGO_TILED, uniforms=uni, rebin_interval=8)
+    mass0 = rec[:, 7].copy()
+    history = []
+    for block in range(20):
+        h.set_uniforms(**dict(uni, time=block * 100 / 60))
+        h.step(100, 1 / 60)
+        cell = h.download_grid_i32()
+        p = h.download_particles()
+        total_mass = int(cell[:, 3].astype(np.int64).sum())
+        history.append(total_mass)
+        assert n * 10_000_000 - 40 * n <= total_mass <= n * 10_000_000 + 40 * n
+        assert p.shape[0] == n and np.array_equal(p[:, 7], mass0)
+        assert np.isfinite(p[:, :23]).all()
+        assert (p[:, 0:3] >= 2.0).all() and (p[:, 0:3] <= np.array(grid, np.float32) - 2.0).all()
+        # updateGrid stores momentum / mass per live cell; multiplying back reproduces the
+        # decoded fixed-point momentum to rounding (sanity link between the two grids)
+        f = h.download_grid_f32()
+        interior = (f[:, 3] > 0)
+        back = f[interior, 0:3].astype(np.float64) * f[interior, 3:4].astype(np.float64)
+        fixed = cell[interior, 0:3].astype(np.float64) / 1e7
+        zeroed = (f[interior, 0:3] == 0)          # boundary band components are zeroed by updateGrid
+        assert np.allclose(np.where(zeroed, fixed, back), fixed, rtol=1e-5, atol=1e-6)
+    assert max(history) - min(history) < 40 * n
+    h.close()
