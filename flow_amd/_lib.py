@@ -23,6 +23,9 @@ FIELD_WIDTH = {FIELD_POSITION: 3, FIELD_VELOCITY: 3, FIELD_DENSITY: 1, FIELD_COL
 PLANE_LOW_HALO, PLANE_LOW_OWNED, PLANE_HIGH_OWNED, PLANE_HIGH_HALO = range(4)
 COMP_MOMENTUM, COMP_MASS, COMP_ALL = 0x7, 0x8, 0xF
 MIGRATE_WORDS = 24
+SEGMENTS = 9
+# Order of the population-segment entries in ModeUniforms (SIM:761-1313).
+SEGMENT_NAMES = ("Pink", "Purple", "Cyan", "Teal", "DarkBlue", "DarkPurple", "DarkRed", "Orange", "LightGreen")
 
 # Every symbol include/flowmpm.h declares.
 EXPORTS = (
@@ -33,7 +36,7 @@ EXPORTS = (
     "flowmpm_get_local_grid", "flowmpm_download_grid_i32", "flowmpm_download_grid_f32",
     "flowmpm_set_profiling", "flowmpm_get_timings", "flowmpm_reset_timings", "flowmpm_plane_bytes",
     "flowmpm_plane_add_i32", "flowmpm_plane_copy_out", "flowmpm_extract_leavers",
-    "flowmpm_insert_arrivals",
+    "flowmpm_insert_arrivals", "flowmpm_set_mode_uniforms",
 )
 
 
@@ -60,6 +63,38 @@ class Uniforms(ctypes.Structure):
         ("hide_percentage", ctypes.c_float),
         ("grid_mode", ctypes.c_uint32),
         ("front_gravity_mode", ctypes.c_uint32),
+    ]
+
+
+class ModeUniforms(ctypes.Structure):
+    """flowmpm_mode_uniforms."""
+
+    _fields_ = [
+        ("cylinder_mode", ctypes.c_uint32), ("sphere_containment_mode", ctypes.c_uint32),
+        ("polygon_containment_mode", ctypes.c_uint32), ("color_spheres_mode", ctypes.c_uint32),
+        ("two_color_sphere_mode", ctypes.c_uint32),
+        ("segment_mode", ctypes.c_uint32 * SEGMENTS),
+        ("cylinder_radius", ctypes.c_float), ("cylinder_center_x", ctypes.c_float),
+        ("cylinder_center_y", ctypes.c_float),
+        ("sphere_radius", ctypes.c_float), ("sphere_center", ctypes.c_float * 3),
+        ("polygon_vertex_count", ctypes.c_uint32),
+        ("polygon_vertices", (ctypes.c_float * 2) * 16),
+        ("color_spheres_boost_time", ctypes.c_float), ("color_spheres_boost_duration", ctypes.c_float),
+        ("color_sphere_radius", ctypes.c_float),
+        ("color_sphere_positions", (ctypes.c_float * 3) * 13),
+        ("palette_colors", (ctypes.c_float * 3) * 13),
+        ("segment_boost_time", ctypes.c_float * SEGMENTS),
+        ("segment_boost_duration", ctypes.c_float * SEGMENTS),
+        ("segment_main_radius", ctypes.c_float * SEGMENTS),
+        ("segment_sphere_radius", ctypes.c_float * SEGMENTS),
+        ("segment_sphere_center", (ctypes.c_float * 3) * SEGMENTS),
+        ("segment_negative_center", (ctypes.c_float * 3) * SEGMENTS),
+        ("negative_space_sphere_radius", ctypes.c_float),
+        ("grid_width", ctypes.c_uint32), ("grid_height", ctypes.c_uint32),
+        ("grid_start_x", ctypes.c_float), ("grid_start_y", ctypes.c_float),
+        ("grid_spacing_x", ctypes.c_float), ("grid_spacing_y", ctypes.c_float),
+        ("grid_z", ctypes.c_float), ("grid_random_offset", ctypes.c_float),
+        ("grid_noise_strength", ctypes.c_float),
     ]
 
 
@@ -117,6 +152,7 @@ def load():
         "flowmpm_plane_copy_out": ([vp, i32, vp], ctypes.c_int),
         "flowmpm_extract_leavers": ([vp, ip, i32, vp, i64, i64p], ctypes.c_int),
         "flowmpm_insert_arrivals": ([vp, vp, i64], ctypes.c_int),
+        "flowmpm_set_mode_uniforms": ([vp, ctypes.POINTER(ModeUniforms)], ctypes.c_int),
     }
     for name, (argtypes, restype) in protos.items():
         fn = getattr(L, name)

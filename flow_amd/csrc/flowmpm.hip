@@ -34,6 +34,9 @@ struct flowmpm_sim {
     flowmpm_config cfg{};
     mpm::Params params{};
     flowmpm_uniforms uniforms{};
+    flowmpm_mode_uniforms modes{};
+    mpm::ModeParams *d_modes = nullptr;   // device copy g2p's mode instantiation reads
+    bool modes_stale = true;              // d_modes differs from `modes` / the two mode flags
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool slab = false;
@@ -248,20 +251,56 @@ int stage_update_grid(flowmpm_sim *s)
     return timing_end(s, t);
 }
 
+// True when any uniform that selects a mode branch of g2p is set.
+bool any_mode_on(const flowmpm_sim *s)
+{
+    const flowmpm_mode_uniforms &m = s->modes;
+    bool on = s->uniforms.grid_mode != 0 || s->uniforms.front_gravity_mode != 0 || m.cylinder_mode != 0 ||
+              m.sphere_containment_mode != 0 || m.polygon_containment_mode != 0 || m.color_spheres_mode != 0 ||
+              m.two_color_sphere_mode != 0;
+    for (int k = 0; k < FLOWMPM_SEGMENTS; k++) on = on || m.segment_mode[k] != 0;
+    return on;
+}
+
+// Stream-ordered refresh of the device copy: the record travels as a kernel argument, so no
+// host buffer has to outlive the call.
+__global__ void store_modes_kernel(mpm::ModeParams value, mpm::ModeParams *dst)
+{
+    const unsigned *src = reinterpret_cast<const unsigned *>(&value);
+    unsigned *out = reinterpret_cast<unsigned *>(dst);
+    for (unsigned i = threadIdx.x; i < sizeof(mpm::ModeParams) / sizeof(unsigned); i += blockDim.x) out[i] = src[i];
+}
+
 int stage_g2p(flowmpm_sim *s)
 {
     int rc;
     if (is_tiled(s) && (rc = stage_rebin_if_needed(s))) return rc;
+    const mpm::ModeParams *modes = nullptr;
+    if (any_mode_on(s)) {
+        if (s->modes_stale) {
+            mpm::ModeParams value;
+            value.u = s->modes;
+            value.grid_mode = s->uniforms.grid_mode;
+            value.front_gravity_mode = s->uniforms.front_gravity_mode;
+            hipLaunchKernelGGL(store_modes_kernel, dim3(1), dim3(256), 0, s->stream, value, s->d_modes);
+            if ((rc = launch_check(s, "store_modes"))) return rc;
+            s->modes_stale = false;
+        }
+        modes = s->d_modes;
+    }
     size_t t;
     if ((rc = timing_begin(s, FLOWMPM_KERNEL_G2P, &t))) return rc;
     if (s->live > 0) {
         if (is_tiled(s)) {
-            if ((rc = mpm::launch_g2p_tiled(s->tiled, s->store, s->live, s->cellf, s->params, s->stream)))
+            if ((rc = mpm::launch_g2p_tiled(s->tiled, s->store, s->live, s->cellf, s->params, modes, s->stream)))
                 return fail(s, FLOWMPM_ERR_HIP, "g2p_tiled launch failed");
             s->tiled.steps_since_rebin += 1;
+        } else if (modes) {
+            hipLaunchKernelGGL(mpm::g2p_gather_kernel<true>, dim3(blocks_for(s->live, 256)), dim3(256), 0,
+                               s->stream, s->store, s->live, s->cellf, s->params, modes);
         } else {
-            hipLaunchKernelGGL(mpm::g2p_gather_kernel, dim3(blocks_for(s->live, 256)), dim3(256), 0,
-                               s->stream, s->store, s->live, s->cellf, s->params);
+            hipLaunchKernelGGL(mpm::g2p_gather_kernel<false>, dim3(blocks_for(s->live, 256)), dim3(256), 0,
+                               s->stream, s->store, s->live, s->cellf, s->params, modes);
         }
         if ((rc = launch_check(s, "g2p"))) return rc;
     }
@@ -287,10 +326,6 @@ int stage_rebin_if_needed(flowmpm_sim *s)
 
 int validate_uniforms(flowmpm_sim *s, const flowmpm_uniforms *u)
 {
-    if (u->grid_mode != 0)
-        return fail(s, FLOWMPM_ERR_UNSUPPORTED, "gridMode != 0 (image modes) is not implemented");
-    if (u->front_gravity_mode != 0)
-        return fail(s, FLOWMPM_ERR_UNSUPPORTED, "frontGravityMode != 0 is not implemented");
     if (u->hide_percentage != 0.0f)
         return fail(s, FLOWMPM_ERR_UNSUPPORTED, "hidePercentage != 0 is not implemented");
     if (u->cursor_interaction > 1u)
@@ -425,6 +460,8 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         HIP_TRY(s, hipMemsetAsync(s->cell, 0, (size_t)s->local_cells * sizeof(int4), s->stream));
         HIP_TRY(s, hipMemsetAsync(s->mass_i, 0, (size_t)s->local_cells * sizeof(int), s->stream));
         HIP_TRY(s, hipMemsetAsync(s->cellf, 0, (size_t)s->local_cells * sizeof(float4), s->stream));
+        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->d_modes), sizeof(mpm::ModeParams)));
+        HIP_TRY(s, hipMemsetAsync(s->d_modes, 0, sizeof(mpm::ModeParams), s->stream));
         int r = alloc_store(s, &s->store);
         if (r) return r;
         if (c.algorithm != FLOWMPM_ALGO_SCATTER) {
@@ -461,6 +498,7 @@ int flowmpm_destroy(flowmpm_sim *s)
     if (s->cell) (void)hipFree(s->cell);
     if (s->mass_i) (void)hipFree(s->mass_i);
     if (s->cellf) (void)hipFree(s->cellf);
+    if (s->d_modes) (void)hipFree(s->d_modes);
     if (s->mig_counters) (void)hipFree(s->mig_counters);
     if (s->mig_lists) (void)hipFree(s->mig_lists);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -498,8 +536,20 @@ int flowmpm_set_uniforms(flowmpm_sim *s, const flowmpm_uniforms *u)
     if (!s || !u) return fail(s, FLOWMPM_ERR_INVALID, "null argument");
     int rc = validate_uniforms(s, u);
     if (rc) return rc;
+    if (u->grid_mode != s->uniforms.grid_mode || u->front_gravity_mode != s->uniforms.front_gravity_mode)
+        s->modes_stale = true;
     s->uniforms = *u;
     refresh_params(s);
+    return FLOWMPM_OK;
+}
+
+int flowmpm_set_mode_uniforms(flowmpm_sim *s, const flowmpm_mode_uniforms *m)
+{
+    if (!s || !m) return fail(s, FLOWMPM_ERR_INVALID, "null argument");
+    if (m->polygon_vertex_count > 16u)
+        return fail(s, FLOWMPM_ERR_INVALID, "polygonVertexCount above the 16 vertex uniforms");
+    s->modes = *m;
+    s->modes_stale = true;
     return FLOWMPM_OK;
 }
 

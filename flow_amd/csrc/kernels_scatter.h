@@ -6,6 +6,7 @@
 #pragma once
 
 #include "mpm_device.h"
+#include "mpm_modes.h"
 
 namespace mpm {
 
@@ -164,9 +165,12 @@ update_grid_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass_i
     }
 }
 
-// SIM:431-1536, chaos path, gathering straight from the global float grid.
+// SIM:431-1536, gathering straight from the global float grid.  MODES = false is the chaos
+// path (every mode uniform zero, M unused); MODES = true adds the mode branches.
+template <bool MODES>
 __global__ void __launch_bounds__(256)
-g2p_gather_kernel(Store st, long long n, const float4 *__restrict__ cellf, Params P)
+g2p_gather_kernel(Store st, long long n, const float4 *__restrict__ cellf, Params P,
+                  const ModeParams *__restrict__ M)
 {
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -175,13 +179,19 @@ g2p_gather_kernel(Store st, long long n, const float4 *__restrict__ cellf, Param
     in.mass = st.slot(kMass)[j];
     in.dirx = st.slot(kDirX)[j]; in.diry = st.slot(kDirY)[j]; in.dirz = st.slot(kDirZ)[j];
 
-    Vec3 v = g2p_pre_forces(in.px, in.py, in.pz, P);
+    Vec3 v;
+    if (MODES)
+        v = g2p_pre_forces_modes(in.px, in.py, in.pz, st.slot(kColR)[j], st.slot(kColG)[j], st.slot(kColB)[j],
+                                 st.ids()[j], P, M);
+    else
+        v = g2p_pre_forces(in.px, in.py, in.pz, P);
     Stencil s = make_stencil(in.px, in.py, in.pz);
     float B[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) B[k] = 0.0f;
+    const bool gather = !MODES || M->grid_mode == 0u;   // SIM:1322: no gather in grid mode
 #pragma unroll
-    for (int gx = 0; gx < 3; gx++)
+    for (int gx = 0; gx < 3 && gather; gx++)
 #pragma unroll
         for (int gy = 0; gy < 3; gy++) {
             float wxy = s.wx[gx] * s.wy[gy];
@@ -198,7 +208,7 @@ g2p_gather_kernel(Store st, long long n, const float4 *__restrict__ cellf, Param
                 v.x = v.x + wvx; v.y = v.y + wvy; v.z = v.z + wvz;
             }
         }
-    G2POut o = g2p_finish(in, v, B, P);
+    G2POut o = MODES ? g2p_finish_modes(in, v, B, P, M) : g2p_finish(in, v, B, P);
 #pragma unroll
     for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
     st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;

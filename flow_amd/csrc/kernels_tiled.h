@@ -616,7 +616,7 @@ p2g_momentum_tiled_kernel(Store st, const int4 *__restrict__ items, const int *_
     flush_arena<3>(lds, A, P, g);
 }
 
-// ---- g2p (SIM:431-1536, chaos path) -----------------------------------------------
+// ---- g2p (SIM:431-1536; MODES as in g2p_gather_kernel) ------------------------------
 
 template <bool INSIDE>
 __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid, int abase,
@@ -658,9 +658,11 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
         }
 }
 
+template <bool MODES>
 __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_G2P_WAVES)
 g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                 TileDims td, const float4 *__restrict__ cellf, Params P, Stragglers sg)
+                 TileDims td, const float4 *__restrict__ cellf, Params P, Stragglers sg,
+                 const ModeParams *__restrict__ M)
 {
     const int item_id = item_for_block(*n_items);
     if (item_id < 0) return;
@@ -691,18 +693,23 @@ g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict
         Stencil s = make_stencil(in.px, in.py, in.pz);
         int abase;
         if (stencil_in_arena(s, A, &abase)) {
-            Vec3 v = g2p_pre_forces(in.px, in.py, in.pz, P);
+            Vec3 v;
+            if (MODES)
+                v = g2p_pre_forces_modes(in.px, in.py, in.pz, st.slot(kColR)[j], st.slot(kColG)[j],
+                                         st.slot(kColB)[j], st.ids()[j], P, M);
+            else
+                v = g2p_pre_forces(in.px, in.py, in.pz, P);
 #if FLOWMPM_G2P_PHASE_BARRIERS
             __builtin_amdgcn_sched_barrier(0);     // let the noise temporaries die before the gather
 #endif
             float B[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) B[k] = 0.0f;
-            g2p_gather<true>(s, grid, abase, cellf, P, v, B);
+            if (!MODES || M->grid_mode == 0u) g2p_gather<true>(s, grid, abase, cellf, P, v, B);
 #if FLOWMPM_G2P_PHASE_BARRIERS
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            G2POut o = g2p_finish(in, v, B, P);
+            G2POut o = MODES ? g2p_finish_modes(in, v, B, P, M) : g2p_finish(in, v, B, P);
 #pragma unroll
             for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
             st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;
@@ -743,8 +750,10 @@ straggler_p2g_kernel(Store st, Stragglers sg, FixedGrid g, Params P)
     }
 }
 
+template <bool MODES>
 __global__ void __launch_bounds__(256)
-straggler_g2p_kernel(Store st, Stragglers sg, const float4 *__restrict__ cellf, Params P)
+straggler_g2p_kernel(Store st, Stragglers sg, const float4 *__restrict__ cellf, Params P,
+                     const ModeParams *__restrict__ M)
 {
     const int count = *sg.count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
@@ -753,13 +762,18 @@ straggler_g2p_kernel(Store st, Stragglers sg, const float4 *__restrict__ cellf, 
         in.px = st.slot(kPosX)[j]; in.py = st.slot(kPosY)[j]; in.pz = st.slot(kPosZ)[j];
         in.mass = st.slot(kMass)[j];
         in.dirx = st.slot(kDirX)[j]; in.diry = st.slot(kDirY)[j]; in.dirz = st.slot(kDirZ)[j];
-        Vec3 v = g2p_pre_forces(in.px, in.py, in.pz, P);
+        Vec3 v;
+        if (MODES)
+            v = g2p_pre_forces_modes(in.px, in.py, in.pz, st.slot(kColR)[j], st.slot(kColG)[j], st.slot(kColB)[j],
+                                     st.ids()[j], P, M);
+        else
+            v = g2p_pre_forces(in.px, in.py, in.pz, P);
         Stencil s = make_stencil(in.px, in.py, in.pz);
         float B[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) B[k] = 0.0f;
-        g2p_gather<false>(s, nullptr, 0, cellf, P, v, B);
-        G2POut o = g2p_finish(in, v, B, P);
+        if (!MODES || M->grid_mode == 0u) g2p_gather<false>(s, nullptr, 0, cellf, P, v, B);
+        G2POut o = MODES ? g2p_finish_modes(in, v, B, P, M) : g2p_finish(in, v, B, P);
 #pragma unroll
         for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
         st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;
@@ -875,10 +889,24 @@ inline int launch_p2g_momentum_tiled(TiledState &T, Store st, long long n, Fixed
     FLOWMPM_TILED_STAGE(p2g_momentum_tiled_kernel, straggler_p2g_kernel<3>, g);
 }
 
+// modes == nullptr: chaos path.
 inline int launch_g2p_tiled(TiledState &T, Store st, long long n, const float4 *cellf, const Params &P,
-                            hipStream_t stream)
+                            const ModeParams *modes, hipStream_t stream)
 {
-    FLOWMPM_TILED_STAGE(g2p_tiled_kernel, straggler_g2p_kernel, cellf);
+    if (hipMemsetAsync(T.stragglers.count, 0, sizeof(int), stream) != hipSuccess) return 1;
+    const dim3 grid(item_bound(T, n)), block(kTiledThreads);
+    if (modes) {
+        hipLaunchKernelGGL(g2p_tiled_kernel<true>, grid, block, 0, stream, st, T.items, T.n_items, tile_dims(T),
+                           cellf, P, T.stragglers, modes);
+        hipLaunchKernelGGL(straggler_g2p_kernel<true>, dim3(kStragglerBlocks), dim3(256), 0, stream, st,
+                           T.stragglers, cellf, P, modes);
+    } else {
+        hipLaunchKernelGGL(g2p_tiled_kernel<false>, grid, block, 0, stream, st, T.items, T.n_items, tile_dims(T),
+                           cellf, P, T.stragglers, modes);
+        hipLaunchKernelGGL(straggler_g2p_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, st,
+                           T.stragglers, cellf, P, modes);
+    }
+    return 0;
 }
 
 }  // namespace mpm

@@ -189,15 +189,13 @@ __device__ __forceinline__ float wall(float xn, float v, float wall_max)
     return v;
 }
 
-// Everything after the gather.  B[3*col + row] is the gathered affine sum.
-__device__ __forceinline__ G2POut g2p_finish(const G2PIn &in, Vec3 v, const float B[9],
-                                             const Params &P)
+// The mouse force (SIM:1354-1360).
+__device__ __forceinline__ Vec3 g2p_mouse(const G2PIn &in, Vec3 v, const Params &P)
 {
-    float px = in.px, py = in.py, pz = in.pz;
-    if (P.cursor_interaction == 1u) {      // SIM:1354-1360
-        float bx = px * 1.0f - P.ray_origin[0];
-        float by = py * 1.0f - P.ray_origin[1];
-        float bz = pz * 0.4f - P.ray_origin[2];
+    if (P.cursor_interaction == 1u) {
+        float bx = in.px * 1.0f - P.ray_origin[0];
+        float by = in.py * 1.0f - P.ray_origin[1];
+        float bz = in.pz * 0.4f - P.ray_origin[2];
         float cx = P.ray_dir[1] * bz - P.ray_dir[2] * by;
         float cy = P.ray_dir[2] * bx - P.ray_dir[0] * bz;
         float cz = P.ray_dir[0] * by - P.ray_dir[1] * bx;
@@ -209,6 +207,14 @@ __device__ __forceinline__ G2POut g2p_finish(const G2PIn &in, Vec3 v, const floa
         v.z = v.z + (P.mouse_force[2] * 1.0f) * force;
         v.x = v.x * in.mass; v.y = v.y * in.mass; v.z = v.z * in.mass;
     }
+    return v;
+}
+
+// C = B * 4, integration, clamp, soft walls, direction (SIM:1362, 1515-1533).
+// B[3*col + row] is the gathered affine sum.
+__device__ __forceinline__ G2POut g2p_integrate(const G2PIn &in, Vec3 v, const float B[9], const Params &P)
+{
+    float px = in.px, py = in.py, pz = in.pz;
     G2POut o;
 #pragma unroll
     for (int k = 0; k < 9; k++) o.C[k] = B[k] * 4.0f;          // SIM:1362
@@ -228,6 +234,12 @@ __device__ __forceinline__ G2POut g2p_finish(const G2PIn &in, Vec3 v, const floa
     o.diry = in.diry * (1.0f - 0.1f) + v.y * 0.1f;
     o.dirz = in.dirz * (1.0f - 0.1f) + v.z * 0.1f;
     return o;
+}
+
+// Everything after the gather on the chaos path.
+__device__ __forceinline__ G2POut g2p_finish(const G2PIn &in, Vec3 v, const float B[9], const Params &P)
+{
+    return g2p_integrate(in, g2p_mouse(in, v, P), B, P);
 }
 
 }  // namespace mpm

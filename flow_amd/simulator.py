@@ -17,6 +17,7 @@ import numpy as np
 
 from . import _lib
 from .conf import conf as default_conf
+from .modes import ModeHost
 from .particles import reference_scene
 from .structured_array import PARTICLE_STRUCT, StructuredArray
 
@@ -95,6 +96,10 @@ class Handle:
         u.hide_percentage = hide_percentage
         u.grid_mode, u.front_gravity_mode = int(grid_mode), int(front_gravity_mode)
         self._chk(self.L.flowmpm_set_uniforms(self._h, ctypes.byref(u)))
+
+    def set_mode_uniforms(self, modes):
+        """`modes` is a _lib.ModeUniforms record."""
+        self._chk(self.L.flowmpm_set_mode_uniforms(self._h, ctypes.byref(modes)))
 
     def step(self, n_steps=1, dtime=0.0):
         self._chk(self.L.flowmpm_step(self._h, int(n_steps), float(dtime)))
@@ -237,7 +242,8 @@ class MlsMpmSimulator:
     fixedPointMultiplier = 1e7          # SIM:43
 
     def __init__(self, renderer=None, conf=None, device=0, algorithm=_lib.ALGO_TILED, rebin_interval=4,
-                 seed=0xF10E5EED):
+                 seed=0xF10E5EED, clock=None):
+        self.clock = clock               # stands in for Date.now(), milliseconds (SIM:1827, 2428)
         self.renderer = renderer         # kept for signature parity; unused (SIM:71-73)
         self.conf = conf if conf is not None else default_conf
         self.device = device
@@ -277,6 +283,7 @@ class MlsMpmSimulator:
         u.cursorInteraction = Uniform(0)
         u.hidePercentage = Uniform(0.0)
         u.time = Uniform(0.0)            # three.js TSL `time` node (SIM:22, 1318)
+        self.modes = ModeHost(u, Uniform, Vector3, clock=self.clock)     # SIM:154-254
         self.handle = Handle(grid, max_particles, device=self.device, algorithm=self.algorithm,
                              rebin_interval=self.rebin_interval)
         self.handle.upload_particles(self.particleBuffer.records())
@@ -291,12 +298,26 @@ class MlsMpmSimulator:
         self.uniforms.mouseRayOrigin.value.copy(origin)
         self.mousePos.copy(pos)
 
+    def toggleGridMode(self, mode, image=None):
+        """SIM:1776-2421.  Image modes (1, 2, 7) take the decoded image as an array
+        [height, width, >= 3] uint8 or the path of a binary PPM file.  The simulated state and
+        the colours g2p reads stay as they are (see modes.py); getColors() returns the
+        rewritten colours from now on."""
+        colors = self.particleBuffer.records()[:, 24:27]
+        self.modes.toggle(int(mode), colors, self.conf.particles, image=image)
+
+    @property
+    def gridMode(self):
+        return self.modes.gridMode
+
     def update(self, interval, elapsed):
         """SIM:2423-2541: one frame = one step.  `elapsed` supplies the clock that the
         reference's noise reads from three.js's `time` node."""
         c = self.conf
         u = self.uniforms
+        self.modes.update_boost_clocks()                                 # SIM:2426-2494
         u.noise.value = c.noise                                          # SIM:2496-2511
+        u.gridNoiseStrength.value = c.gridNoiseStrength
         u.stiffness.value = c.stiffness
         u.gravityType.value = c.gravity
         u.gravity.value.set(0, 0, 0)
@@ -336,6 +357,7 @@ class MlsMpmSimulator:
             mouse_force=u.mouseForce.value.toArray(),
             cursor_interaction=u.cursorInteraction.value, hide_percentage=u.hidePercentage.value,
             grid_mode=u.gridMode.value, front_gravity_mode=u.frontGravityMode.value)
+        self.handle.set_mode_uniforms(self.modes.pack())
 
     # ---- what the reference's renderers bind (particleRenderer.js:119-133,
     # pointRenderer.js:17-19), as host arrays in particle-id order ----
@@ -349,13 +371,19 @@ class MlsMpmSimulator:
         return self.handle.download_field(_lib.FIELD_DENSITY)
 
     def getColors(self):
+        """What material.colorNode reads: the device colours until toggleGridMode first
+        rebinds the material to a rewritten buffer (SIM:2376-2384)."""
+        if self.modes.render_colors is not None:
+            return self.modes.render_colors[:self.numParticles].copy()
         return self.handle.download_field(_lib.FIELD_COLOR)
 
     def readAoS(self):
         """All maxParticles records in the reference's 28-float layout; also refreshes
         particleBuffer.floatArray."""
         rec = self.handle.download_particles()
-        self.particleBuffer.records()[:rec.shape[0]] = rec
+        host = self.particleBuffer.records()
+        host[:rec.shape[0], :24] = rec[:, :24]      # colours stay the host's (toggleGridMode rewrites them)
+        host[:rec.shape[0], 27] = rec[:, 27]
         return rec
 
     def synchronize(self):

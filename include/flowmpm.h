@@ -114,10 +114,49 @@ typedef struct {
     float mouse_ray_origin[3];        /* SIM:257, 1544 */
     float mouse_force[3];             /* SIM:258, 2533 */
     uint32_t cursor_interaction;      /* SIM:259 */
-    float hide_percentage;            /* SIM:260; must be 0 */
-    uint32_t grid_mode;               /* SIM:152; must be 0 */
-    uint32_t front_gravity_mode;      /* SIM:153; must be 0 */
+    float hide_percentage;            /* SIM:260; must be 0 (FLOWMPM_ERR_UNSUPPORTED otherwise) */
+    uint32_t grid_mode;               /* SIM:152, read at SIM:444 */
+    uint32_t front_gravity_mode;      /* SIM:153, read at SIM:485, 1316, 1365 */
 } flowmpm_uniforms;
+
+/* The mode uniforms g2p reads for its containment / attraction forces (SIM:154-254).
+ * Entry k of the segment arrays is the k-th population-segment mode in the order of
+ * SIM:761-1313: pink, purple, cyan, teal, dark blue, dark purple, dark red, orange,
+ * light green (uniforms populationSegment<Name>Mode, ...BoostTime, ...BoostDuration,
+ * populationMainSphereRadius<Name>, <name>SphereCenterX/Y/Z, <name>SphereRadius,
+ * <name>NegativeSpaceCenterX/Y/Z).  All zero after flowmpm_create. */
+#define FLOWMPM_SEGMENTS 9
+typedef struct {
+    uint32_t cylinder_mode;                 /* SIM:154 */
+    uint32_t sphere_containment_mode;       /* SIM:158 */
+    uint32_t polygon_containment_mode;      /* SIM:159 */
+    uint32_t color_spheres_mode;            /* SIM:160 */
+    uint32_t two_color_sphere_mode;         /* SIM:161 */
+    uint32_t segment_mode[FLOWMPM_SEGMENTS];              /* SIM:162-170 */
+    float cylinder_radius, cylinder_center_x, cylinder_center_y;   /* SIM:155-157 */
+    float sphere_radius;                    /* SIM:233 */
+    float sphere_center[3];                 /* SIM:236-238 */
+    uint32_t polygon_vertex_count;          /* SIM:172; at most 16 */
+    float polygon_vertices[16][2];          /* SIM:173-176 */
+    float color_spheres_boost_time;         /* SIM:177 */
+    float color_spheres_boost_duration;     /* SIM:178 */
+    float color_sphere_radius;              /* SIM:235 */
+    float color_sphere_positions[13][3];    /* SIM:240-242 */
+    float palette_colors[13][3];            /* SIM:243-245 */
+    float segment_boost_time[FLOWMPM_SEGMENTS];           /* SIM:179-195, odd lines */
+    float segment_boost_duration[FLOWMPM_SEGMENTS];       /* SIM:180-196, even lines */
+    float segment_main_radius[FLOWMPM_SEGMENTS];          /* SIM:225-232, 234 */
+    float segment_sphere_radius[FLOWMPM_SEGMENTS];        /* SIM:197-213, odd lines */
+    float segment_sphere_center[FLOWMPM_SEGMENTS][3];     /* SIM:198-214, even lines */
+    float segment_negative_center[FLOWMPM_SEGMENTS][3];   /* SIM:216-224 */
+    float negative_space_sphere_radius;     /* SIM:215 */
+    uint32_t grid_width, grid_height;       /* SIM:246-247 */
+    float grid_start_x, grid_start_y;       /* SIM:248-249 */
+    float grid_spacing_x, grid_spacing_y;   /* SIM:250-251 */
+    float grid_z;                           /* SIM:252 */
+    float grid_random_offset;               /* SIM:253 */
+    float grid_noise_strength;              /* SIM:254 */
+} flowmpm_mode_uniforms;
 
 typedef struct {
     double  ms[FLOWMPM_TIMING_SLOTS];        /* summed HIP-event time per slot */
@@ -147,6 +186,12 @@ int flowmpm_get_num_particles(flowmpm_sim *sim, int64_t *live, int64_t *resident
 
 /* The uniform writes of update() (SIM:2496-2534). */
 int flowmpm_set_uniforms(flowmpm_sim *sim, const flowmpm_uniforms *u);
+
+/* The uniform writes of toggleGridMode and its set-up helpers (SIM:1679-2493) and the
+ * per-frame boost clocks (SIM:2500-2521).  While every mode flag here and gridMode /
+ * frontGravityMode are 0, g2p runs its plain path and these values are never read.
+ * polygon_vertex_count > 16 is FLOWMPM_ERR_INVALID. */
+int flowmpm_set_mode_uniforms(flowmpm_sim *sim, const flowmpm_mode_uniforms *m);
 
 /* renderer.computeAsync([...5 kernels]) (SIM:2538-2539), `n_steps` times.  The clock
  * of step k is (float)(uniforms.time + k * dtime).  Asynchronous: returns after

@@ -40,6 +40,41 @@ class Uniforms(ctypes.Structure):
     ]
 
 
+SEGMENTS = 9
+
+
+class ModeUniforms(ctypes.Structure):
+    """Mirror of orc_mode_uniforms (oracle/mpm_oracle.h)."""
+
+    _fields_ = [
+        ("cylinder_mode", ctypes.c_uint32), ("sphere_containment_mode", ctypes.c_uint32),
+        ("polygon_containment_mode", ctypes.c_uint32), ("color_spheres_mode", ctypes.c_uint32),
+        ("two_color_sphere_mode", ctypes.c_uint32),
+        ("segment_mode", ctypes.c_uint32 * SEGMENTS),
+        ("cylinder_radius", ctypes.c_float), ("cylinder_center_x", ctypes.c_float),
+        ("cylinder_center_y", ctypes.c_float),
+        ("sphere_radius", ctypes.c_float), ("sphere_center", ctypes.c_float * 3),
+        ("polygon_vertex_count", ctypes.c_uint32),
+        ("polygon_vertices", (ctypes.c_float * 2) * 16),
+        ("color_spheres_boost_time", ctypes.c_float), ("color_spheres_boost_duration", ctypes.c_float),
+        ("color_sphere_radius", ctypes.c_float),
+        ("color_sphere_positions", (ctypes.c_float * 3) * 13),
+        ("palette_colors", (ctypes.c_float * 3) * 13),
+        ("segment_boost_time", ctypes.c_float * SEGMENTS),
+        ("segment_boost_duration", ctypes.c_float * SEGMENTS),
+        ("segment_main_radius", ctypes.c_float * SEGMENTS),
+        ("segment_sphere_radius", ctypes.c_float * SEGMENTS),
+        ("segment_sphere_center", (ctypes.c_float * 3) * SEGMENTS),
+        ("segment_negative_center", (ctypes.c_float * 3) * SEGMENTS),
+        ("negative_space_sphere_radius", ctypes.c_float),
+        ("grid_width", ctypes.c_uint32), ("grid_height", ctypes.c_uint32),
+        ("grid_start_x", ctypes.c_float), ("grid_start_y", ctypes.c_float),
+        ("grid_spacing_x", ctypes.c_float), ("grid_spacing_y", ctypes.c_float),
+        ("grid_z", ctypes.c_float), ("grid_random_offset", ctypes.c_float),
+        ("grid_noise_strength", ctypes.c_float),
+    ]
+
+
 def build(force=False):
     """Compile the oracle with gcc (a no-op when the .so is newer than its sources)."""
     srcs = [os.path.join(_HERE, f) for f in ("mpm_oracle.c", "mpm_oracle.h", "Makefile")]
@@ -70,6 +105,9 @@ def lib():
         L.orc_update_grid.argtypes = [ip, fp, up]
         L.orc_g2p.argtypes = [fp, fp, up]
         L.orc_step.argtypes = [fp, ip, fp, up]
+        mp = ctypes.POINTER(ModeUniforms)
+        L.orc_g2p_modes.argtypes = [fp, fp, up, mp]
+        L.orc_step_modes.argtypes = [fp, ip, fp, up, mp]
         L.orc_run.argtypes = [fp, ip, fp, up, ctypes.c_int, ctypes.c_double]
         L.orc_tri_noise3d.argtypes = [fp, ctypes.c_float, ctypes.c_float, fp]
         _lib = L
@@ -89,7 +127,7 @@ def _ip(a):
 def make_uniforms(grid, num_particles, dt=0.1, stiffness=3.0, rest_density=2.5,
                   dynamic_viscosity=0.1, noise=1.0, time=0.0,
                   mouse_ray_direction=(0.0, 0.0, 0.0), mouse_ray_origin=(0.0, 0.0, 0.0),
-                  mouse_force=(0.0, 0.0, 0.0), cursor_interaction=0):
+                  mouse_force=(0.0, 0.0, 0.0), cursor_interaction=0, grid_mode=0, front_gravity_mode=0):
     u = Uniforms()
     u.grid_x, u.grid_y, u.grid_z = (int(g) for g in grid)
     u.num_particles = int(num_particles)
@@ -100,8 +138,8 @@ def make_uniforms(grid, num_particles, dt=0.1, stiffness=3.0, rest_density=2.5,
     u.mouse_force[:] = mouse_force
     u.cursor_interaction = int(cursor_interaction)
     u.hide_percentage = 0.0
-    u.grid_mode = 0
-    u.front_gravity_mode = 0
+    u.grid_mode = int(grid_mode)
+    u.front_gravity_mode = int(front_gravity_mode)
     return u
 
 
@@ -143,6 +181,15 @@ class Oracle:
     def step(self, particles, u):
         self._t()
         self.L.orc_step(_fp(particles), _ip(self.cell), _fp(self.cellf), ctypes.byref(u))
+
+    def g2p_modes(self, particles, u, modes):
+        self._t()
+        self.L.orc_g2p_modes(_fp(particles), _fp(self.cellf), ctypes.byref(u), ctypes.byref(modes))
+
+    def step_modes(self, particles, u, modes):
+        self._t()
+        self.L.orc_step_modes(_fp(particles), _ip(self.cell), _fp(self.cellf), ctypes.byref(u),
+                              ctypes.byref(modes))
 
     def run(self, particles, u, n_steps, dtime):
         self._t()

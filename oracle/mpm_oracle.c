@@ -337,6 +337,290 @@ void orc_g2p(float *particles, const float *cellf, const orc_uniforms *u)
     for (int64_t i = 0; i < n; i++) g2p_one(particles + i * ORC_STRIDE, cellf, u);
 }
 
+
+/* ---- g2p with the mode branches ------------------------------------------------------- */
+
+/* Colours the nine population-segment modes compare against (SIM:766, 847, 906, 965, 1024,
+ * 1083, 1142, 1201, 1260), in the order of the mode uniforms. */
+static const float k_segment_color[ORC_SEGMENTS][3] = {
+    { 1.0f, 0.3372549f, 0.717647f }, { 0.737f, 0.588f, 0.976f }, { 0.773f, 0.941f, 0.949f },
+    { 0.0f, 0.455f, 0.529f },        { 0.082f, 0.224f, 0.263f }, { 0.137f, 0.137f, 0.337f },
+    { 0.314f, 0.071f, 0.102f },      { 1.0f, 0.392f, 0.145f },   { 0.839f, 0.957f, 0.600f },
+};
+
+static inline float length3(const float v[3]) { return sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+/* boostTime / boostDuration clamped, smoothstep-eased (SIM:751-753 and its copies). */
+static inline float eased_boost(float boost_time, float boost_duration)
+{
+    float bp = clampf(boost_time / boost_duration, 0.0f, 1.0f);
+    return (bp * bp) * (3.0f - bp * 2.0f);
+}
+
+/* v += (direction * strength) * dt */
+static inline void push(float v[3], const float dir[3], float strength, float dt)
+{
+    for (int a = 0; a < 3; a++) v[a] = v[a] + (dir[a] * strength) * dt;
+}
+
+/* "Outside the sphere -> push back in" (SIM:517-528, 535-546, 740-758, 773-794 ...).
+ * boosted: strength = (excess * 0.3) * mix(1, 20, eased); plain: strength = excess * 0.3. */
+static inline void contain_in_sphere(float v[3], const float pos[3], const float center[3], float radius,
+                                     int boosted, float eased, float dt)
+{
+    float to[3] = { pos[0] - center[0], pos[1] - center[1], pos[2] - center[2] };
+    float dist = length3(to);
+    if (dist > radius) {
+        float toward[3] = { -(to[0] / dist), -(to[1] / dist), -(to[2] / dist) };
+        float excess = dist - radius;
+        float strength = excess * 0.3f;
+        if (boosted) strength = strength * (1.0f * (1.0f - eased) + 20.0f * eased);
+        push(v, toward, strength, dt);
+    }
+}
+
+/* "Inside the negative-space sphere -> push out" (SIM:821-840 and its copies). */
+static inline void repel_from_sphere(float v[3], const float pos[3], const float center[3], float radius,
+                                     float eased, float dt)
+{
+    float to[3] = { pos[0] - center[0], pos[1] - center[1], pos[2] - center[2] };
+    float dist = length3(to);
+    if (dist < radius) {
+        float away[3] = { to[0] / dist, to[1] / dist, to[2] / dist };
+        float depth = radius - dist;
+        float strength = (depth * 0.3f) * (1.0f * (1.0f - eased) + 20.0f * eased);
+        push(v, away, strength, dt);
+    }
+}
+
+static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc_uniforms *u,
+                          const orc_mode_uniforms *m)
+{
+    float particle_mass = P[ORC_MASS];
+    float pos[3] = { P[ORC_POS], P[ORC_POS + 1], P[ORC_POS + 2] };
+    const float color[3] = { P[ORC_COLOR], P[ORC_COLOR + 1], P[ORC_COLOR + 2] };
+    float v[3] = { 0.0f, 0.0f, 0.0f };
+    const float gs[3] = { (float)u->grid_x, (float)u->grid_y, (float)u->grid_z };
+    const int gsi[3] = { u->grid_x, u->grid_y, u->grid_z };
+    const float dt = u->dt;
+
+    if (u->grid_mode == 1u) {
+        /* SIM:445-482 attraction to a target on the image grid */
+        int32_t gw = (int32_t)m->grid_width;
+        int32_t gxi = gw ? index % gw : 0;         /* WGSL: x % 0 = 0, x / 0 = x */
+        int32_t gyi = gw ? index / gw : index;
+        float hash = ((float)index * 12.9898f + (float)gxi * 78.233f) + (float)gyi * 37.719f;
+        float random_x = fractf(hash) * 2.0f - 1.0f;
+        float random_y = fractf(hash * 43758.5453f) * 2.0f - 1.0f;
+        float offset_x = (random_x * m->grid_spacing_x) * m->grid_random_offset;
+        float offset_y = (random_y * m->grid_spacing_y) * m->grid_random_offset;
+        float target[3] = { (m->grid_start_x + (float)gxi * m->grid_spacing_x) + offset_x,
+                            (m->grid_start_y + (float)gyi * m->grid_spacing_y) + offset_y, m->grid_z };
+        float np[3] = { pos[0] * 0.92f, pos[1] * 0.92f, pos[2] * 0.92f }, n[3];
+        orc_tri_noise3d(np, 1.15f, u->time, n);
+        for (int a = 0; a < 3; a++) target[a] = target[a] + (n[a] * m->grid_noise_strength) * 2.0f;
+        float zp[3] = { pos[0] * 0.85f + 100.0f, pos[1] * 0.85f + 200.0f, pos[2] * 0.85f + 300.0f }, zn[3];
+        orc_tri_noise3d(zp, 0.02f, u->time, zn);
+        target[2] = target[2] + (zn[2] * m->grid_noise_strength) * 2.0f;
+        float to[3] = { target[0] - pos[0], target[1] - pos[1], target[2] - pos[2] };
+        float dist = length3(to);
+        float dir[3] = { to[0] / dist, to[1] / dist, to[2] / dist };
+        push(v, dir, dist * 10.0f, dt);
+    } else if (u->front_gravity_mode == 1u) {
+        /* SIM:485-488: pull toward -z */
+        const float front[3] = { 0.0f, 0.0f, -1.0f };
+        for (int a = 0; a < 3; a++) v[a] = v[a] + (front[a] * 0.1f) * dt;
+    } else {
+        /* SIM:490-492 centre gravity */
+        float pn[3];
+        for (int a = 0; a < 3; a++) pn[a] = pos[a] / (float)(gsi[a] - 1) - 0.5f;
+        normalize3(pn);
+        for (int a = 0; a < 3; a++) v[a] = v[a] - (pn[a] * 0.1f) * dt;
+    }
+
+    /* SIM:497-511 cylinder repulsion */
+    if (m->cylinder_mode == 1u) {
+        float to[3] = { pos[0] - m->cylinder_center_x, pos[1] - m->cylinder_center_y, pos[2] - pos[2] };
+        float flat[3] = { to[0], to[1], 0.0f };
+        float dist = length3(flat);
+        if (dist < m->cylinder_radius) {
+            float dir[3] = { flat[0] / dist, flat[1] / dist, flat[2] / dist };
+            float strength = (1.0f - dist / m->cylinder_radius) * 0.5f;
+            push(v, dir, strength, dt);
+        }
+    }
+    /* SIM:514-529 sphere containment, SIM:532-547 two-colour sphere */
+    if (m->sphere_containment_mode == 1u) contain_in_sphere(v, pos, m->sphere_center, m->sphere_radius, 0, 0.0f, dt);
+    if (m->two_color_sphere_mode == 1u) contain_in_sphere(v, pos, m->sphere_center, m->sphere_radius, 0, 0.0f, dt);
+
+    /* SIM:550-696 polygon containment in the xy plane */
+    if (m->polygon_containment_mode == 1u) {
+        const float px = pos[0], py = pos[1];
+        int inside = 0;
+        const int count = (int)m->polygon_vertex_count;
+        for (int i = 0; i < count; i++) {
+            int j = (i == count - 1) ? 0 : i + 1;
+            const float *v0 = m->polygon_vertices[i < 15 ? i : 15];
+            const float *v1 = m->polygon_vertices[j < 15 ? j : 15];
+            int above0 = v0[1] > py, above1 = v1[1] > py;
+            if (above0 != above1) {
+                float t = (py - v0[1]) / (v1[1] - v0[1]);
+                float x_intersect = v0[0] + (v1[0] - v0[0]) * t;
+                if (x_intersect > px) inside = (inside + 1) % 2;
+            }
+        }
+        if (inside == 0) {
+            float min_dist = 9999.0f, nearest[2] = { 0.0f, 0.0f };
+            for (int i = 0; i < count; i++) {
+                int j = (i == count - 1) ? 0 : i + 1;
+                const float *v0 = m->polygon_vertices[i < 15 ? i : 15];
+                const float *v1 = m->polygon_vertices[j < 15 ? j : 15];
+                float edge[2] = { v1[0] - v0[0], v1[1] - v0[1] };
+                float to_p[2] = { px - v0[0], py - v0[1] };
+                float edge_len = sqrtf(edge[0] * edge[0] + edge[1] * edge[1]);
+                float edge_len_sq = edge_len * edge_len;
+                float t = (edge_len_sq < 0.0001f)
+                              ? 0.0f
+                              : clampf((to_p[0] * edge[0] + to_p[1] * edge[1]) / edge_len_sq, 0.0f, 1.0f);
+                float closest[2] = { v0[0] + edge[0] * t, v0[1] + edge[1] * t };
+                float dx = px - closest[0], dy = py - closest[1];
+                float dist = sqrtf(dx * dx + dy * dy);
+                if (dist < min_dist) { min_dist = dist; nearest[0] = closest[0]; nearest[1] = closest[1]; }
+            }
+            float to[3] = { nearest[0] - pos[0], nearest[1] - pos[1], pos[2] - pos[2] };
+            float dist = length3(to);
+            float dir[3] = { to[0] / dist, to[1] / dist, to[2] / dist };
+            push(v, dir, dist * 0.3f, dt);
+        }
+    }
+
+    /* SIM:699-759 colour spheres */
+    if (m->color_spheres_mode == 1u) {
+        float min_dist = 999.0f;
+        int closest = 0;
+        for (int i = 0; i < 10; i++) {
+            const float *pc = m->palette_colors[i < 9 ? i : 9];
+            float d[3] = { color[0] - pc[0], color[1] - pc[1], color[2] - pc[2] };
+            float dist = length3(d);
+            if (dist < min_dist) { min_dist = dist; closest = i; }
+        }
+        contain_in_sphere(v, pos, m->color_sphere_positions[closest < 9 ? closest : 9], m->color_sphere_radius, 1,
+                          eased_boost(m->color_spheres_boost_time, m->color_spheres_boost_duration), dt);
+    }
+
+    /* SIM:762-1313 population segments: main sphere for everyone, a smaller sphere for the
+     * segment's colour, and a negative-space sphere that repels */
+    for (int k = 0; k < ORC_SEGMENTS; k++) {
+        if (m->segment_mode[k] != 1u) continue;
+        float cd[3] = { color[0] - k_segment_color[k][0], color[1] - k_segment_color[k][1],
+                        color[2] - k_segment_color[k][2] };
+        int is_segment = length3(cd) < 0.1f;
+        float eased = eased_boost(m->segment_boost_time[k], m->segment_boost_duration[k]);
+        contain_in_sphere(v, pos, m->sphere_center, m->segment_main_radius[k], 1, eased, dt);
+        if (is_segment)
+            contain_in_sphere(v, pos, m->segment_sphere_center[k], m->segment_sphere_radius[k], 1, eased, dt);
+        repel_from_sphere(v, pos, m->segment_negative_center[k], m->negative_space_sphere_radius, eased, dt);
+    }
+
+    /* SIM:1317-1320 noise, only outside grid and front-gravity mode */
+    if (u->grid_mode == 0u && u->front_gravity_mode == 0u) {
+        float np[3] = { pos[0] * 0.015f, pos[1] * 0.015f, pos[2] * 0.015f }, n[3];
+        orc_tri_noise3d(np, u->time, 0.11f, n);
+        for (int a = 0; a < 3; a++) n[a] = n[a] - 0.285f;
+        normalize3(n);
+        for (int a = 0; a < 3; a++) n[a] = n[a] * 0.28f;
+        for (int a = 0; a < 3; a++) v[a] = v[a] - (n[a] * u->noise) * dt;
+    }
+
+    /* SIM:1322-1352 gather, skipped in grid mode */
+    float B[3][3] = { { 0 } };
+    if (u->grid_mode == 0u) {
+        int ci[3];
+        float w[3][3];
+        bspline(pos, ci, w);
+        for (int gx = 0; gx < 3; gx++)
+            for (int gy = 0; gy < 3; gy++)
+                for (int gz = 0; gz < 3; gz++) {
+                    float weight = (w[gx][0] * w[gy][1]) * w[gz][2];
+                    int cx = ci[0] + gx, cy = ci[1] + gy, cz = ci[2] + gz;
+                    float d[3] = { ((float)cx + 0.5f) - pos[0], ((float)cy + 0.5f) - pos[1],
+                                   ((float)cz + 0.5f) - pos[2] };
+                    const float *f = cellf + 4 * (int64_t)cell_ptr(cx, cy, cz, u);
+                    float wv[3] = { f[0] * weight, f[1] * weight, f[2] * weight };
+                    for (int c = 0; c < 3; c++)
+                        for (int r = 0; r < 3; r++) B[c][r] = B[c][r] + wv[r] * d[c];
+                    for (int r = 0; r < 3; r++) v[r] = v[r] + wv[r];
+                }
+    }
+
+    /* SIM:1355-1360 mouse force */
+    if (u->grid_mode == 0u && u->cursor_interaction == 1u) {
+        const float *rd = u->mouse_ray_direction, *ro = u->mouse_ray_origin;
+        float b[3] = { pos[0] * 1.0f - ro[0], pos[1] * 1.0f - ro[1], pos[2] * 0.4f - ro[2] };
+        float cr[3] = { rd[1] * b[2] - rd[2] * b[1], rd[2] * b[0] - rd[0] * b[2], rd[0] * b[1] - rd[1] * b[0] };
+        float f = fmaxf(1.0f - length3(cr) * 0.1f, 0.0f);
+        float force = f * f;
+        for (int a = 0; a < 3; a++) v[a] = v[a] + (u->mouse_force[a] * 1.0f) * force;
+        for (int a = 0; a < 3; a++) v[a] = v[a] * particle_mass;
+    }
+
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) P[ORC_C + 4 * c + r] = B[c][r] * 4.0f;      /* SIM:1362 */
+
+    /* SIM:1365-1476 damping */
+    if (u->front_gravity_mode == 1u)
+        for (int a = 0; a < 3; a++) v[a] = v[a] * 0.98f;
+    if (m->color_spheres_mode == 1u) {
+        float e = eased_boost(m->color_spheres_boost_time, m->color_spheres_boost_duration);
+        float damping = 0.98f * (1.0f - e) + 0.7f * e;
+        for (int a = 0; a < 3; a++) v[a] = v[a] * damping;
+    }
+    for (int k = 0; k < ORC_SEGMENTS; k++) {
+        if (m->segment_mode[k] != 1u) continue;
+        float e = eased_boost(m->segment_boost_time[k], m->segment_boost_duration[k]);
+        float damping = 0.98f * (1.0f - e) + 0.7f * e;
+        for (int a = 0; a < 3; a++) v[a] = v[a] * damping;
+    }
+
+    /* SIM:1515-1533 */
+    for (int a = 0; a < 3; a++) {
+        pos[a] = pos[a] + v[a] * dt;
+        pos[a] = fminf(fmaxf(pos[a], 2.0f), (float)(gsi[a] - 2));
+    }
+    for (int a = 0; a < 3; a++) {
+        float xn = pos[a] + (v[a] * dt) * 3.0f;
+        float wall_min = 3.0f, wall_max = gs[a] - 3.0f;
+        if (xn < wall_min) v[a] = v[a] + (wall_min - xn) * 0.3f;
+        if (xn > wall_max) v[a] = v[a] + (wall_max - xn) * 0.3f;
+    }
+    for (int a = 0; a < 3; a++) {
+        P[ORC_POS + a] = pos[a];
+        P[ORC_VEL + a] = v[a];
+        P[ORC_DIR + a] = P[ORC_DIR + a] * (1.0f - 0.1f) + v[a] * 0.1f;
+    }
+}
+
+void orc_g2p_modes(float *particles, const float *cellf, const orc_uniforms *u, const orc_mode_uniforms *m)
+{
+    static const orc_mode_uniforms zero_modes;
+    if (!m) m = &zero_modes;
+    int64_t n = u->num_particles;
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+    for (int64_t i = 0; i < n; i++) g2p_modes_one(particles + i * ORC_STRIDE, (int32_t)i, cellf, u, m);
+}
+
+void orc_step_modes(float *particles, int32_t *cell, float *cellf, const orc_uniforms *u,
+                    const orc_mode_uniforms *m)
+{
+    int64_t count = (int64_t)u->grid_x * u->grid_y * u->grid_z;
+    orc_clear_grid(cell, cellf, count);
+    orc_p2g1(particles, cell, u);
+    orc_p2g2(particles, cell, u);
+    orc_update_grid(cell, cellf, u);
+    orc_g2p_modes(particles, cellf, u, m);
+}
+
 /* SIM:2538-2539 */
 void orc_step(float *particles, int32_t *cell, float *cellf, const orc_uniforms *u)
 {

@@ -16,6 +16,11 @@
  * must agree bit for bit, and (b) implementation-independent properties of the
  * reference's arithmetic (see tests/test_oracle.py).
  *
+ * The mode branches of g2p (orc_g2p_modes) are restated by this C file only (no numpy twin).
+ * The hide-percentage edge parking (SIM:1479-1513) is NOT restated: `gridSize.x.mul(0.1)`
+ * multiplies an int uniform by a float literal, and whether three.js 0.176 emits that as
+ * i32(0.1) = 0 or as a float product cannot be settled without three.js itself.
+ *
  * Arithmetic conventions (WGSL semantics, which is what three.js emits):
  *   - i32(f32): truncate toward zero, saturating, NaN -> 0
  *   - fract(x) = x - floor(x);  mix(a,b,t) = a*(1-t) + b*t
@@ -53,9 +58,33 @@ typedef struct {
     float mouse_force[3];                /* :258 */
     uint32_t cursor_interaction;         /* :259 */
     float hide_percentage;               /* :260 (only 0 is restated) */
-    uint32_t grid_mode;                  /* :152 (only 0 is restated) */
-    uint32_t front_gravity_mode;         /* :153 (only 0 is restated) */
+    uint32_t grid_mode;                  /* :152 (orc_g2p ignores it; orc_g2p_modes honours it) */
+    uint32_t front_gravity_mode;         /* :153 (as grid_mode) */
 } orc_uniforms;
+
+/* The mode uniforms read by g2p's art-direction forces (SIM:152-254).  Index k of the
+ * segment arrays is the population segment in the reference's order: pink, purple, cyan,
+ * teal, dark blue, dark purple, dark red, orange, light green (SIM:761-1313). */
+#define ORC_SEGMENTS 9
+typedef struct {
+    uint32_t cylinder_mode, sphere_containment_mode, polygon_containment_mode;
+    uint32_t color_spheres_mode, two_color_sphere_mode;
+    uint32_t segment_mode[ORC_SEGMENTS];
+    float cylinder_radius, cylinder_center_x, cylinder_center_y;          /* SIM:155-157 */
+    float sphere_radius, sphere_center[3];                                /* SIM:233, 236-238 */
+    uint32_t polygon_vertex_count;                                        /* SIM:172 */
+    float polygon_vertices[16][2];                                        /* SIM:173-176 */
+    float color_spheres_boost_time, color_spheres_boost_duration;         /* SIM:177-178 */
+    float color_sphere_radius;                                            /* SIM:235 */
+    float color_sphere_positions[13][3], palette_colors[13][3];           /* SIM:240-245 */
+    float segment_boost_time[ORC_SEGMENTS], segment_boost_duration[ORC_SEGMENTS];
+    float segment_main_radius[ORC_SEGMENTS], segment_sphere_radius[ORC_SEGMENTS];
+    float segment_sphere_center[ORC_SEGMENTS][3], segment_negative_center[ORC_SEGMENTS][3];
+    float negative_space_sphere_radius;                                   /* SIM:215 */
+    uint32_t grid_width, grid_height;                                     /* SIM:246-247 */
+    float grid_start_x, grid_start_y, grid_spacing_x, grid_spacing_y;     /* SIM:248-251 */
+    float grid_z, grid_random_offset, grid_noise_strength;                /* SIM:252-254 */
+} orc_mode_uniforms;
 
 /* threads <= 1: plain scalar loops.  threads > 1: OpenMP, one iteration per
  * particle / cell as the reference dispatches them, relaxed atomic adds. */
@@ -67,6 +96,13 @@ void orc_p2g1(const float *particles, int32_t *cell, const orc_uniforms *u);
 void orc_p2g2(float *particles, int32_t *cell, const orc_uniforms *u);
 void orc_update_grid(const int32_t *cell, float *cellf, const orc_uniforms *u);
 void orc_g2p(float *particles, const float *cellf, const orc_uniforms *u);
+/* g2p with every mode branch of SIM:431-1536 except the hide-percentage edge parking
+ * (SIM:441-442, 1479-1513; u->hide_percentage must be 0).  u->grid_mode and
+ * u->front_gravity_mode are honoured.  m == NULL means all mode uniforms are zero. */
+void orc_g2p_modes(float *particles, const float *cellf, const orc_uniforms *u,
+                   const orc_mode_uniforms *m);
+void orc_step_modes(float *particles, int32_t *cell, float *cellf, const orc_uniforms *u,
+                    const orc_mode_uniforms *m);
 
 /* One reference update(): the five kernels in submission order
  * (mlsMpmSimulator.js:2538-2539). */

@@ -81,9 +81,32 @@ def noise_vectors():
         json.dump(rows, f, indent=1)
 
 
+def mode_digests():
+    """Three steps per mode case of tests/mode_cases.py: digests of the particle records
+    plus the first two records' bits."""
+    import mode_cases
+    n, steps = 4096, 3
+    base = dict(dt=0.1, stiffness=3.0, rest_density=2.5, dynamic_viscosity=0.1, noise=1.0, time=0.375)
+    rows = {}
+    for name in mode_cases.ALL_CASES:
+        uni, fields = mode_cases.case(name)
+        u = binding.make_uniforms(mode_cases.GRID, n, **dict(base, **uni))
+        m = mode_cases.fill(binding.ModeUniforms, fields)
+        rec = mode_cases.particles(n)
+        orc = binding.Oracle(mode_cases.GRID)
+        for _ in range(steps):
+            orc.step_modes(rec, u, m)
+        rows[name] = {"sha256_particles": hashlib.sha256(rec.tobytes()).hexdigest(),
+                      "first_records_bits": [int(x) for x in rec[:2].view(np.uint32).ravel()]}
+    with open(os.path.join(HERE, "mode_cases.json"), "w") as f:
+        json.dump({"grid": mode_cases.GRID, "particles": n, "steps": steps, "uniforms": base, "cases": rows},
+                  f, indent=1)
+
+
 if __name__ == "__main__":
     binding.build()
     small_case()
     default_scene_digest()
     noise_vectors()
+    mode_digests()
     print("golden vectors written to", HERE)

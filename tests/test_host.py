@@ -87,6 +87,9 @@ class _FakeHandle:
     def set_uniforms(self, **kw):
         self.uniform_calls.append(kw)
 
+    def set_mode_uniforms(self, modes):
+        self.mode_uniforms = modes
+
     def step(self, n, dtime):
         self.steps += n
 
