@@ -114,6 +114,9 @@ class GpuSlabBackend:
     def set_uniforms(self, **kw):
         self.handle.set_uniforms(**kw)
 
+    def set_mode_uniforms(self, modes):
+        self.handle.set_mode_uniforms(modes)
+
     def run_kernel(self, kernel_id):
         self.handle.run_kernel(kernel_id)
 
@@ -179,6 +182,11 @@ class SlabSimulation:
     # ---- set-up ----
     def set_uniforms(self, **kw):
         self.backend.set_uniforms(**kw)
+
+    def set_mode_uniforms(self, modes):
+        """The mode uniforms act per particle (keyed on the particle id, which migrates with
+        the particle), so every slab takes the same record."""
+        self.backend.set_mode_uniforms(modes)
 
     def scatter_initial_particles(self, records, ids):
         """Every rank brings any subset of the global particles; each record is routed to the

@@ -178,6 +178,34 @@ napi_value SetUniforms(napi_env env, napi_callback_info info)
     return nullptr;
 }
 
+// setModeUniforms(handle, ArrayBuffer): the buffer holds one flowmpm_mode_uniforms record
+// (host_js/modes.js packs it; every field is a 4-byte word, so there is no padding).
+napi_value SetModeUniforms(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    flowmpm_sim *sim = unwrap(env, argv[0]);
+    if (!sim) return nullptr;
+    void *data = nullptr;
+    size_t bytes = 0;
+    if (napi_get_arraybuffer_info(env, argv[1], &data, &bytes) != napi_ok || bytes != sizeof(flowmpm_mode_uniforms)) {
+        napi_throw_type_error(env, nullptr, "expected an ArrayBuffer of sizeof(flowmpm_mode_uniforms) bytes");
+        return nullptr;
+    }
+    flowmpm_mode_uniforms m;
+    std::memcpy(&m, data, sizeof m);
+    int rc = flowmpm_set_mode_uniforms(sim, &m);
+    if (rc != FLOWMPM_OK) return throw_flowmpm(env, sim, rc);
+    return nullptr;
+}
+
+napi_value ModeUniformsSize(napi_env env, napi_callback_info)
+{
+    napi_value out;
+    NAPI_OK(napi_create_int32(env, (int32_t)sizeof(flowmpm_mode_uniforms), &out));
+    return out;
+}
+
 napi_value Step(napi_env env, napi_callback_info info)
 {
     napi_value argv[3];
@@ -280,6 +308,8 @@ napi_value Init(napi_env env, napi_value exports)
         {"uploadParticles", nullptr, UploadParticles, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"setNumParticles", nullptr, SetNumParticles, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"setUniforms", nullptr, SetUniforms, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"setModeUniforms", nullptr, SetModeUniforms, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"modeUniformsSize", nullptr, ModeUniformsSize, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"synchronize", nullptr, Synchronize, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"downloadParticles", nullptr, DownloadParticles, nullptr, nullptr, nullptr, napi_default, nullptr},

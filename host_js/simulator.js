@@ -10,6 +10,7 @@ const { Vector3 } = require('./vector3');
 const { StructuredArray, PARTICLE_STRUCT } = require('./structured_array');
 const { conf: defaultConf } = require('./config');
 const { referenceScene } = require('./particles');
+const { ModeHost } = require('./modes');
 
 let addon = null;
 function native() {
@@ -37,7 +38,11 @@ class MlsMpmSimulator {
         this.mousePosArray = [];
         this.particleBuffer = null;
         this.handle = null;
+        this.clock = o.clock || null;            // stands in for Date.now() (SIM:1827, 2428)
+        this.modes = null;
     }
+
+    get gridMode() { return this.modes ? this.modes.gridMode : false; }
 
     async init() {
         const maxParticles = this.conf.maxParticles;
@@ -52,6 +57,7 @@ class MlsMpmSimulator {
         u.mouseRayDirection = uniform(new Vector3()); u.mouseRayOrigin = uniform(new Vector3());
         u.mouseForce = uniform(new Vector3()); u.cursorInteraction = uniform(0); u.hidePercentage = uniform(0.0);
         u.time = uniform(0.0);                   // three.js TSL `time` node (SIM:22, 1318)
+        this.modes = new ModeHost(u, this.clock);                         // SIM:154-254
         this.handle = native().create({ gridX: 128, gridY: 64, gridZ: 64, maxParticles, device: this.device,
             algorithm: this.algorithm, rebinInterval: this.rebinInterval });
         native().uploadParticles(this.handle, this.particleBuffer.floatArray, maxParticles);
@@ -66,9 +72,19 @@ class MlsMpmSimulator {
         this.mousePos.copy(pos);
     }
 
+    // SIM:1776-2421.  Image modes (1, 2, 7) take the decoded image {width, height, data[, channels]}.
+    // The simulated state and the colours g2p reads stay as they are (see modes.js);
+    // getColors() returns the rewritten colours from now on.
+    async toggleGridMode(mode, image) {
+        const b = this.particleBuffer;
+        this.modes.toggle(mode, b.floatArray, b.structSize, b.layout.color.offset, this.conf.particles, image);
+    }
+
     async update(interval, elapsed) {            // SIM:2423-2541
         const c = this.conf, u = this.uniforms;
+        this.modes.updateBoostClocks();                                   // SIM:2426-2494
         u.noise.value = c.noise;
+        u.gridNoiseStrength.value = c.gridNoiseStrength;
         u.stiffness.value = c.stiffness;
         u.gravityType.value = c.gravity;
         u.gravity.value.set(0, 0, 0);
@@ -100,6 +116,7 @@ class MlsMpmSimulator {
                 hidePercentage: u.hidePercentage.value, gridMode: u.gridMode.value,
                 frontGravityMode: u.frontGravityMode.value,
             });
+            native().setModeUniforms(this.handle, this.modes.pack());
             native().step(this.handle, 1, 0.0);
         }
     }
@@ -114,12 +131,23 @@ class MlsMpmSimulator {
     getPositions() { return this._field('position', 3); }
     getVelocities() { return this._field('velocity', 3); }
     getDensities() { return this._field('density', 1); }
-    getColors() { return this._field('color', 3); }
+    // What material.colorNode reads: the device colours until toggleGridMode first rebinds the
+    // material to a rewritten buffer (SIM:2376-2384).
+    getColors() {
+        if (this.modes.renderColors) return this.modes.renderColors.slice(0, this.numParticles * 3);
+        return this._field('color', 3);
+    }
 
     // Refreshes particleBuffer.floatArray with all records in the reference's 28-float layout.
+    // The colour floats of the host array stay the host's (toggleGridMode rewrites them).
     readAoS() {
-        native().downloadParticles(this.handle, this.particleBuffer.floatArray);
-        return this.particleBuffer.floatArray;
+        const b = this.particleBuffer, at = b.layout.color.offset;
+        const rec = new Float32Array(b.floatArray.length);
+        native().downloadParticles(this.handle, rec);
+        for (let i = 0; i < rec.length; i += b.structSize)
+            for (let a = 0; a < 3; a++) rec[i + at + a] = b.floatArray[i + at + a];
+        b.floatArray.set(rec);
+        return b.floatArray;
     }
     synchronize() { native().synchronize(this.handle); }
 }

@@ -107,6 +107,7 @@ def lib():
         L.orc_step.argtypes = [fp, ip, fp, up]
         mp = ctypes.POINTER(ModeUniforms)
         L.orc_g2p_modes.argtypes = [fp, fp, up, mp]
+        L.orc_g2p_modes_ids.argtypes = [fp, ip, fp, up, mp]
         L.orc_step_modes.argtypes = [fp, ip, fp, up, mp]
         L.orc_run.argtypes = [fp, ip, fp, up, ctypes.c_int, ctypes.c_double]
         L.orc_tri_noise3d.argtypes = [fp, ctypes.c_float, ctypes.c_float, fp]
@@ -182,9 +183,14 @@ class Oracle:
         self._t()
         self.L.orc_step(_fp(particles), _ip(self.cell), _fp(self.cellf), ctypes.byref(u))
 
-    def g2p_modes(self, particles, u, modes):
+    def g2p_modes(self, particles, u, modes, ids=None):
+        """ids: the reference buffer index of each record (default: its position)."""
         self._t()
-        self.L.orc_g2p_modes(_fp(particles), _fp(self.cellf), ctypes.byref(u), ctypes.byref(modes))
+        if ids is None:
+            self.L.orc_g2p_modes(_fp(particles), _fp(self.cellf), ctypes.byref(u), ctypes.byref(modes))
+        else:
+            self.L.orc_g2p_modes_ids(_fp(particles), _ip(ids), _fp(self.cellf), ctypes.byref(u),
+                                     ctypes.byref(modes))
 
     def step_modes(self, particles, u, modes):
         self._t()

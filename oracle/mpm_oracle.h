@@ -101,6 +101,10 @@ void orc_g2p(float *particles, const float *cellf, const orc_uniforms *u);
  * u->front_gravity_mode are honoured.  m == NULL means all mode uniforms are zero. */
 void orc_g2p_modes(float *particles, const float *cellf, const orc_uniforms *u,
                    const orc_mode_uniforms *m);
+/* The same over a subset of the reference's buffer: ids[i] is the instanceIndex of record i
+ * (a slab of a decomposed run holds particles in arbitrary order).  ids == NULL: i itself. */
+void orc_g2p_modes_ids(float *particles, const int32_t *ids, const float *cellf, const orc_uniforms *u,
+                       const orc_mode_uniforms *m);
 void orc_step_modes(float *particles, int32_t *cell, float *cellf, const orc_uniforms *u,
                     const orc_mode_uniforms *m);
 

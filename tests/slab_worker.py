@@ -35,6 +35,7 @@ class OracleSlabBackend:
         self.rec = np.zeros((0, 28), np.float32)
         self.ids = np.zeros(0, np.int32)
         self.uniform_kw = {}
+        self.modes = None
         self.plane_words = grid[1] * grid[2] * 4
         self.torch_device = torch.device("cpu")
 
@@ -43,6 +44,9 @@ class OracleSlabBackend:
 
     def set_uniforms(self, **kw):
         self.uniform_kw = kw
+
+    def set_mode_uniforms(self, modes):
+        self.modes = self.binding.ModeUniforms.from_buffer_copy(bytes(modes))
 
     def run_kernel(self, k):
         if k == _lib.KERNEL_CLEAR_GRID:
@@ -54,7 +58,10 @@ class OracleSlabBackend:
         elif k == _lib.KERNEL_UPDATE_GRID:
             self.orc.update_grid(self._u())
         elif k == _lib.KERNEL_G2P:
-            self.orc.g2p(self.rec, self._u())
+            if self.modes is None:
+                self.orc.g2p(self.rec, self._u())
+            else:
+                self.orc.g2p_modes(self.rec, self._u(), self.modes, ids=np.ascontiguousarray(self.ids))
 
     def upload(self, records, ids):
         self.rec, self.ids = np.ascontiguousarray(records, np.float32).copy(), np.asarray(ids, np.int32).copy()
@@ -146,12 +153,20 @@ def main():
     ap.add_argument("--vel", type=float, default=3.0)
     ap.add_argument("--balanced", action="store_true")
     ap.add_argument("--algorithm", choices=("tiled", "scatter"), default="tiled")
+    ap.add_argument("--mode-case", default=None, help="a case name of tests/mode_cases.py (grid 128,64,64)")
     args = ap.parse_args()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     grid = tuple(int(g) for g in args.grid.split(","))
     n = args.particles
-    rec = moving_particles(n, grid, seed=41, vel=args.vel)       # every rank builds the same scene
+    mode_uni, mode_fields = {}, None
+    if args.mode_case:
+        import mode_cases
+        assert grid == mode_cases.GRID
+        mode_uni, mode_fields = mode_cases.case(args.mode_case)
+        rec = mode_cases.particles(n, seed=41, vel=args.vel)
+    else:
+        rec = moving_particles(n, grid, seed=41, vel=args.vel)   # every rank builds the same scene
     lo, hi = rank * n // world, (rank + 1) * n // world          # and contributes one id range
     if args.balanced:
         starts = balanced_plane_starts(rec[lo:hi, 0], grid[0], world, dist)
@@ -166,8 +181,10 @@ def main():
         sim = SlabSimulation(grid, starts, rank, world, max_particles=n, device=0, algorithm=algo,
                              rebin_interval=2, dist=dist)
     sim.scatter_initial_particles(rec[lo:hi], np.arange(lo, hi, dtype=np.int32))
+    if mode_fields is not None:
+        sim.set_mode_uniforms(mode_cases.fill(_lib.ModeUniforms, mode_fields))
     for k in range(args.steps):
-        sim.set_uniforms(**dict(DEFAULT_UNIFORMS, time=0.25 * k))
+        sim.set_uniforms(**dict(DEFAULT_UNIFORMS, time=0.25 * k, **mode_uni))
         sim.step()
     sim.synchronize()
     out_rec, out_ids = sim.download()

@@ -30,7 +30,8 @@ def test_addon_loads_and_exposes_the_binding():
     out = _node("""
         const m = require('./host_js');
         const names = ['create','uploadParticles','setNumParticles','setUniforms','step','synchronize',
-                       'downloadParticles','downloadField','downloadGridI32','downloadGridF32','deviceCount','version'];
+                       'downloadParticles','downloadField','downloadGridI32','downloadGridF32','deviceCount','version',
+                       'setModeUniforms','modeUniformsSize'];
         const missing = names.filter((n) => typeof m.native()[n] !== 'function');
         console.log(JSON.stringify({missing, version: m.native().version()}));
     """)
@@ -64,6 +65,63 @@ def test_js_host_pieces_agree_with_python_mirror():
     assert d["pos"] == pytest.approx([32, 16, -12.8])
 
 
+def test_js_mode_host_agrees_with_python_mirror():
+    """host_js/modes.js against flow_amd/modes.py: same toggles on the same scripted clock give
+    the same packed mode uniforms and the same rewritten colours."""
+    from flow_amd import modes as host_modes
+    from flow_amd.simulator import Uniform, Vector3, _Uniforms
+    schedule = [6, 9, 13, 17, 4, 8, 18, 5, 0]
+    out = _node("""
+        const m = require('./host_js');
+        const schedule = JSON.parse(process.argv[1]);
+        let now = 1000;
+        const u = {gridMode: {value: 0}, frontGravityMode: {value: 0}};
+        const mh = new m.modes.ModeHost(u, () => now);
+        const n = 50, stride = 28, arr = new Float32Array(64 * stride);
+        const rows = [];
+        for (const mode of schedule) {
+            mh.toggle(mode, arr, stride, 24, n, null);
+            now += 300;
+            mh.updateBoostClocks();
+            const colors = [];
+            for (let i = 0; i < 64; i++) for (let a = 0; a < 3; a++) colors.push(arr[i * stride + 24 + a]);
+            rows.push({pack: Array.from(new Uint32Array(mh.pack())), colors: Array.from(new Uint32Array(new Float32Array(colors).buffer)),
+                       flags: [u.gridMode.value, u.frontGravityMode.value]});
+        }
+        const img = {width: 30, height: 20, channels: 3, data: new Uint8Array(30 * 20 * 3)};
+        for (let i = 0; i < img.data.length; i++) img.data[i] = (i * 37 + 11) % 256;
+        for (const mode of [7, 1]) {
+            mh.toggle(mode, arr, stride, 24, n, img);
+            const colors = [];
+            for (let i = 0; i < 64; i++) for (let a = 0; a < 3; a++) colors.push(arr[i * stride + 24 + a]);
+            rows.push({pack: Array.from(new Uint32Array(mh.pack())), colors: Array.from(new Uint32Array(new Float32Array(colors).buffer)),
+                       flags: [u.gridMode.value, u.frontGravityMode.value]});
+        }
+        console.log(JSON.stringify(rows));
+    """, json.dumps(schedule))
+    rows = json.loads(out)
+    now = [1000.0]
+    u = _Uniforms()
+    u.gridMode, u.frontGravityMode = Uniform(0), Uniform(0)
+    mh = host_modes.ModeHost(u, Uniform, Vector3, clock=lambda: now[0])
+    colors = np.zeros((64, 3), np.float32)
+    img = ((np.arange(30 * 20 * 3) * 37 + 11) % 256).astype(np.uint8).reshape(20, 30, 3)
+    for row, (mode, image) in zip(rows, [(m, None) for m in schedule] + [(7, img), (1, img)]):
+        mh.toggle(mode, colors, 50, image=image)
+        if image is None:
+            now[0] += 300
+            mh.update_boost_clocks()
+        want = np.frombuffer(bytes(mh.pack()), dtype=np.float32)
+        got = np.array(row["pack"], dtype=np.uint32).view(np.float32)
+        # cos / sin of the two hosts may differ in the last place of a double
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-38, err_msg="mode %d" % mode)
+        flags = np.array(row["pack"], dtype=np.uint32)[:14]
+        assert np.array_equal(flags, np.frombuffer(bytes(mh.pack()), dtype=np.uint32)[:14])
+        assert row["flags"] == [u.gridMode.value, u.frontGravityMode.value]
+        got_colors = np.array(row["colors"], dtype=np.uint32).view(np.float32).reshape(64, 3)
+        np.testing.assert_allclose(got_colors, colors, rtol=1e-6, atol=1e-7, err_msg="colours, mode %d" % mode)
+
+
 def test_js_host_refuses_to_run_without_a_gpu():
     out = _node("""
         const m = require('./host_js');
@@ -94,3 +152,40 @@ def test_js_simulator_frame_loop_matches_oracle(oracle_binding, tmp_path):
     assert_bits_equal(got, want, "JS host records after %d frames" % frames)
     pos = np.fromfile(out + ".pos", dtype=np.float32).reshape(particles, 3)
     assert_bits_equal(pos, want[:particles, 0:3], "getPositions()")
+
+
+@pytest.mark.gpu
+def test_js_simulator_toggle_grid_mode_matches_oracle(oracle_binding, tmp_path):
+    """toggleGridMode + update() of the JS class; the oracle is driven with the uniform values
+    the JS host packed for each frame."""
+    out = str(tmp_path / "records.bin")
+    max_particles, particles = 8192, 6000
+    schedule = [[0, 1], [9, 3], [6, 2], [4, 2], [8, 2], [18, 2], [0, 1]]
+    r = subprocess.run([NODE, os.path.join(ROOT, "host_js", "run_frames.js"), out, str(max_particles),
+                        str(particles), "0", json.dumps(schedule)], capture_output=True, text=True, cwd=ROOT,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ob = oracle_binding
+    init = np.fromfile(out + ".init", dtype=np.float32).reshape(max_particles, 28)
+    got = np.fromfile(out, dtype=np.float32).reshape(max_particles, 28)
+    packs = np.fromfile(out + ".modes", dtype=np.uint8)
+    with open(out + ".frames.json") as f:
+        frames = json.load(f)
+    size = packs.size // len(frames)
+    assert size == 940
+    grid = (128, 64, 64)
+    orc = ob.Oracle(grid, threads=4)
+    want = init.copy()
+    rest = 0.25 * max(particles / 8192, 1)
+    for k, fr in enumerate(frames):
+        u = ob.make_uniforms(grid, particles, dt=fr["dt"], stiffness=3.0, rest_density=rest, dynamic_viscosity=0.1,
+                             noise=1.0, time=fr["time"], grid_mode=fr["gridMode"],
+                             front_gravity_mode=fr["frontGravityMode"])
+        m = ob.ModeUniforms.from_buffer_copy(packs[k * size:(k + 1) * size].tobytes())
+        orc.step_modes(want, u, m)
+    assert_bits_equal(got[:, :24], want[:, :24], "JS host records after the mode schedule")
+    from flow_amd.particles import palette_rgb
+    rgb = palette_rgb().astype(np.float32)
+    colors = np.fromfile(out + ".colors", dtype=np.float32).reshape(particles, 3)
+    assert np.array_equal(colors, rgb[np.arange(particles) % 13])
+    assert [fr["frontGravityMode"] for fr in frames][6:8] == [1, 1] and frames[6]["dt"] == pytest.approx(0.4)

@@ -80,6 +80,30 @@ def test_slab_protocol_balanced_boundaries(oracle_binding, tmp_path):
     _check_against_single_domain(tmp_path, 2, rec, orc, grid)
 
 
+def _mode_reference_run(oracle_binding, case_name, n, steps, vel):
+    import mode_cases
+    uni, fields = mode_cases.case(case_name)
+    rec = mode_cases.particles(n, seed=41, vel=vel)
+    orc = oracle_binding.Oracle(mode_cases.GRID, threads=8)
+    m = mode_cases.fill(oracle_binding.ModeUniforms, fields)
+    for k in range(steps):
+        u = oracle_binding.make_uniforms(mode_cases.GRID, n, **dict(DEFAULT_UNIFORMS, time=0.25 * k, **uni))
+        orc.step_modes(rec, u, m)
+    return rec, orc
+
+
+@pytest.mark.parametrize("case_name", ["image_grid", "everything"])
+def test_slab_protocol_with_mode_forces(oracle_binding, tmp_path, case_name):
+    """The mode branches key on the particle's buffer index (grid mode) and colour, both of
+    which must survive migration between slabs."""
+    n, steps, vel = 3000, 6, 4.0
+    _launch(2, tmp_path, "--backend", "oracle", "--grid", "128,64,64", "--particles", str(n),
+            "--steps", str(steps), "--vel", str(vel), "--mode-case", case_name)
+    rec, orc = _mode_reference_run(oracle_binding, case_name, n, steps, vel)
+    moved = _check_against_single_domain(tmp_path, 2, rec, orc, (128, 64, 64))
+    assert moved > 0
+
+
 def test_plane_starts_helpers():
     assert equal_plane_starts(512, 8) == [0, 64, 128, 192, 256, 320, 384, 448, 512]
     x = np.concatenate([np.full(900, 10.5), np.full(100, 50.5)])
@@ -174,4 +198,15 @@ def test_two_rank_rehearsal_on_one_gpu(oracle_binding, tmp_path):
             "--steps", str(steps), "--vel", str(vel))
     rec, orc = _reference_run(oracle_binding, grid, n, steps, vel)
     moved = _check_against_single_domain(tmp_path, 2, rec, orc, grid)
+    assert moved > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case_name", ["image_grid", "everything"])
+def test_two_rank_rehearsal_with_mode_forces(oracle_binding, tmp_path, case_name):
+    n, steps, vel = 20000, 6, 4.0
+    _launch(2, tmp_path, "--backend", "gpu", "--grid", "128,64,64", "--particles", str(n),
+            "--steps", str(steps), "--vel", str(vel), "--mode-case", case_name)
+    rec, orc = _mode_reference_run(oracle_binding, case_name, n, steps, vel)
+    moved = _check_against_single_domain(tmp_path, 2, rec, orc, (128, 64, 64))
     assert moved > 0
