@@ -35,10 +35,15 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--algorithm", choices=("tiled", "tiled_unfused", "scatter"), default="tiled")
-    ap.add_argument("--rebin-interval", type=int, default=8)
+    ap.add_argument("--rebin-interval", type=int, default=64,
+                    help="upper bound of the steps between re-bins; the device re-bins earlier when particles drift")
     ap.add_argument("--particles-log2", type=int, default=24, help="particles per GPU = 2^k")
     ap.add_argument("--grid", type=str, default="", help="override the N=1 grid, e.g. 128,128,128")
     ap.add_argument("--scene", choices=("ellipsoid", "dam_break"), default="ellipsoid")
+    ap.add_argument("--mode", default="chaos",
+                    choices=("chaos", "front_gravity_cylinder", "sphere", "polygon", "color_spheres", "segment",
+                             "image_grid", "everything"),
+                    help="display mode whose g2p forces run in the timed steps (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
@@ -54,6 +59,61 @@ def scene_uniforms(n_particles, grid_cells, scene):
     fill = 0.268 if scene == "ellipsoid" else 0.25
     return dict(dt=0.1, stiffness=3.0, rest_density=n_particles / (fill * grid_cells),
                 dynamic_viscosity=0.1, noise=0.0, time=0.0)
+
+
+def mode_setup(name, grid, n):
+    """(uniform overrides, flowmpm_mode_uniforms) for --mode: the reference's mode geometry
+    (mlsMpmSimulator.js:154-254, 1652-2156), which is laid out for its 128 x 64 x 64 box, scaled
+    to the benchmark grid."""
+    from flow_amd import _lib, modes
+    sx = grid[0] / 128.0
+    centre = (grid[0] / 2.0, grid[1] / 2.0, grid[2] / 2.0)
+    m = _lib.ModeUniforms()
+    m.cylinder_radius, m.cylinder_center_x, m.cylinder_center_y = 44.0 * sx, centre[0], centre[1]
+    m.sphere_radius, m.color_sphere_radius, m.negative_space_sphere_radius = 25.0 * sx, 7.0 * sx, 17.0 * sx
+    m.sphere_center[:] = centre
+    m.color_spheres_boost_duration = modes.COLOR_SPHERES_BOOST_DURATION
+    m.color_spheres_boost_time = 0.7
+    verts = modes.polygon_vertices()
+    m.polygon_vertex_count = len(verts)
+    for i, (x, y) in enumerate(verts):
+        m.polygon_vertices[i][:] = (x * sx, y * grid[1] / 64.0)
+    positions, unique = modes.color_sphere_layout()
+    for i in range(13):
+        if i < len(positions):
+            m.color_sphere_positions[i][:] = [positions[i][a] * grid[a] / (128.0, 64.0, 64.0)[a] for a in range(3)]
+        m.palette_colors[i][:] = [float(c) for c in unique[min(i, len(unique) - 1)]]
+    for k, (sphere_deg, chunk_deg) in enumerate(modes.SEGMENT_ANGLES):
+        a, b = np.deg2rad(sphere_deg), np.deg2rad(chunk_deg)
+        m.segment_boost_duration[k] = modes.COLOR_SPHERES_BOOST_DURATION
+        m.segment_boost_time[k] = 0.7
+        m.segment_main_radius[k], m.segment_sphere_radius[k] = 18.0 * sx, 7.0 * sx
+        m.segment_sphere_center[k][:] = (centre[0] + 40 * sx * np.cos(a), centre[1] + 40 * sx * np.sin(a), centre[2])
+        m.segment_negative_center[k][:] = (centre[0] + 20 * sx * np.cos(b), centre[1] + 20 * sx * np.sin(b), centre[2])
+    gw, gh, start_x, start_y, spacing = modes.image_grid(3, 2, n)
+    m.grid_width, m.grid_height = gw, gh
+    m.grid_start_x, m.grid_start_y = start_x * sx, start_y * grid[1] / 64.0
+    m.grid_spacing_x = m.grid_spacing_y = spacing * sx
+    m.grid_z, m.grid_random_offset, m.grid_noise_strength = centre[2], 0.5, 0.5
+    uni = {}
+    if name == "front_gravity_cylinder":
+        uni["front_gravity_mode"], m.cylinder_mode = 1, 1
+    elif name == "sphere":
+        m.sphere_containment_mode = 1
+    elif name == "polygon":
+        m.polygon_containment_mode = 1
+    elif name == "color_spheres":
+        m.color_spheres_mode = 1
+    elif name == "segment":
+        m.segment_mode[0] = 1
+    elif name == "image_grid":
+        uni["grid_mode"] = 1
+    elif name == "everything":
+        m.cylinder_mode = m.sphere_containment_mode = m.two_color_sphere_mode = 1
+        m.polygon_containment_mode = m.color_spheres_mode = 1
+        for k in range(9):
+            m.segment_mode[k] = 1
+    return uni, m
 
 
 def make_particles(scene, count, grid, seed, first_id=0):
@@ -138,6 +198,11 @@ def run_single(args):
     h = flow_amd.Handle(grid, n, device=0, algorithm=algo, rebin_interval=args.rebin_interval)
     rec = make_particles(args.scene, n, grid, seed)
     h.upload_particles(rec)
+    if args.mode != "chaos":
+        mode_uni, mode_record = mode_setup(args.mode, grid, n)
+        uniforms = dict(uniforms, **mode_uni)
+        h.set_mode_uniforms(mode_record)
+        BYTES["g2p"] = (112, 16)       # the mode branches also read colour (12 B) and id (4 B)
     h.set_uniforms(**uniforms)
 
     def advance(first, count):
@@ -177,7 +242,8 @@ def run_single(args):
         "data": "synthetic",
         "config": {"workload": "16M particles, 256^3 grid, single MI355X" if (args.particles_log2 == 24 and not args.grid)
                    else "%d particles, grid %dx%dx%d, single MI355X" % (n, grid[0], grid[1], grid[2]),
-                   "scene": args.scene, "particles": n, "grid": list(grid), "algorithm": args.algorithm,
+                   "scene": args.scene, "mode": args.mode, "particles": n, "grid": list(grid),
+                   "algorithm": args.algorithm,
                    "rebin_interval": args.rebin_interval, "dt": 0.1, "noise": 0.0,
                    "cursor_interaction": 1 if args.scene == "dam_break" else 0},
         "roofline": roof,
@@ -185,10 +251,11 @@ def run_single(args):
                           "achieved_GBs": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
                           "frac_of_8TBs": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels": per_kernel,
-        "rebin": {"launches": rebin["launches"],
-                  "avg_ms": round(rebin["ms"] / rebin["launches"], 4) if rebin["launches"] else None},
+        # the re-binning sequence is enqueued every step and decides on the device whether to run
+        "rebin": {"performed": rebin.get("performed"), "steps": rebin["launches"],
+                  "avg_ms_per_step": round(rebin["ms"] / rebin["launches"], 4) if rebin["launches"] else None},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.mode == "chaos":
         line["cpu_baseline"] = cpu_baseline(rec, n, grid, uniforms, args.cpu_steps)
     return line
 

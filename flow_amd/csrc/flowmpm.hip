@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,8 +46,8 @@ struct flowmpm_sim {
     long long resident = 0;      // particles on the device
     long long live = 0;          // simulated particles (== resident except set_num_particles)
     long long uploaded = 0;      // records given to upload (single GPU)
-    mpm::Store store{};
-    mpm::Store store_alt{};      // tiled: re-binning target
+    mpm::StoreSel store{};       // tiled: two stores, re-binning gathers from one into the other
+    int drift_divisor = 256;      // re-bin when (particles outside their arena) * divisor > particles
     int4 *cell = nullptr;        // momentum words (word 3 unused on the device)
     int *mass_i = nullptr;       // mass words, one per cell
     mpm::FixedGrid fixed() const { return mpm::FixedGrid{reinterpret_cast<int *>(cell), mass_i}; }
@@ -120,8 +121,9 @@ void refresh_params(flowmpm_sim *s)
 
 // ---- timing -----------------------------------------------------------------
 
-int timing_begin(flowmpm_sim *s, int slot, size_t *idx)
+int timing_begin(flowmpm_sim *s, int slot, size_t *idx, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = s->stream;
     *idx = (size_t)-1;
     if (!s->profiling) return FLOWMPM_OK;
     if (s->events_used == s->events.size()) {
@@ -132,14 +134,14 @@ int timing_begin(flowmpm_sim *s, int slot, size_t *idx)
     }
     *idx = s->events_used++;
     s->events[*idx].slot = slot;
-    HIP_TRY(s, hipEventRecord(s->events[*idx].start, s->stream));
+    HIP_TRY(s, hipEventRecord(s->events[*idx].start, stream));
     return FLOWMPM_OK;
 }
 
-int timing_end(flowmpm_sim *s, size_t idx)
+int timing_end(flowmpm_sim *s, size_t idx, hipStream_t stream = nullptr)
 {
     if (idx == (size_t)-1) return FLOWMPM_OK;
-    HIP_TRY(s, hipEventRecord(s->events[idx].stop, s->stream));
+    HIP_TRY(s, hipEventRecord(s->events[idx].stop, stream ? stream : s->stream));
     return FLOWMPM_OK;
 }
 
@@ -294,7 +296,7 @@ int stage_g2p(flowmpm_sim *s)
         if (is_tiled(s)) {
             if ((rc = mpm::launch_g2p_tiled(s->tiled, s->store, s->live, s->cellf, s->params, modes, s->stream)))
                 return fail(s, FLOWMPM_ERR_HIP, "g2p_tiled launch failed");
-            s->tiled.steps_since_rebin += 1;
+            s->tiled.checked = false;      // the next step decides anew
         } else if (modes) {
             hipLaunchKernelGGL(mpm::g2p_gather_kernel<true>, dim3(blocks_for(s->live, 256)), dim3(256), 0,
                                s->stream, s->store, s->live, s->cellf, s->params, modes);
@@ -312,15 +314,14 @@ int stage_g2p(flowmpm_sim *s)
 int stage_rebin_if_needed(flowmpm_sim *s)
 {
     mpm::TiledState &T = s->tiled;
-    if (T.valid && T.steps_since_rebin < s->cfg.rebin_interval) return FLOWMPM_OK;
-    if (s->live == 0) { T.valid = true; T.steps_since_rebin = 0; return FLOWMPM_OK; }
+    if (T.valid && T.checked) return FLOWMPM_OK;
+    if (s->live == 0) return FLOWMPM_OK;
     size_t t;
     int rc = timing_begin(s, FLOWMPM_TIMING_REBIN, &t);
     if (rc) return rc;
     std::string msg;
-    if (mpm::rebin(T, s->store, s->store_alt, s->live, s->params, s->stream, &msg))
+    if (mpm::rebin_if_due(T, s->store, s->live, s->params, s->cfg.rebin_interval, s->drift_divisor, s->stream, &msg))
         return fail(s, FLOWMPM_ERR_HIP, "rebin: " + msg);
-    std::swap(s->store, s->store_alt);
     return timing_end(s, t);
 }
 
@@ -333,12 +334,12 @@ int validate_uniforms(flowmpm_sim *s, const flowmpm_uniforms *u)
     return FLOWMPM_OK;
 }
 
-int alloc_store(flowmpm_sim *s, mpm::Store *st)
+int alloc_store(flowmpm_sim *s, int which)
 {
-    st->capacity = s->capacity;
+    s->store.capacity = s->capacity;
     size_t bytes = (size_t)mpm::kNumSlots * (size_t)s->capacity * sizeof(float);
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&st->base), bytes));
-    HIP_TRY(s, hipMemsetAsync(st->base, 0, bytes, s->stream));
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->store.base[which]), bytes));
+    HIP_TRY(s, hipMemsetAsync(s->store.base[which], 0, bytes, s->stream));
     return FLOWMPM_OK;
 }
 
@@ -462,13 +463,15 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         HIP_TRY(s, hipMemsetAsync(s->cellf, 0, (size_t)s->local_cells * sizeof(float4), s->stream));
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->d_modes), sizeof(mpm::ModeParams)));
         HIP_TRY(s, hipMemsetAsync(s->d_modes, 0, sizeof(mpm::ModeParams), s->stream));
-        int r = alloc_store(s, &s->store);
+        int r = alloc_store(s, 0);
         if (r) return r;
         if (c.algorithm != FLOWMPM_ALGO_SCATTER) {
-            if ((r = alloc_store(s, &s->store_alt))) return r;
+            if ((r = alloc_store(s, 1))) return r;
             std::string msg;
             if (mpm::tiled_init(s->tiled, s->params, s->capacity, s->stream, &msg))
                 return fail(s, FLOWMPM_ERR_HIP, "tiled_init: " + msg);
+            s->store.cur = &s->tiled.ctl->cur;
+            if (const char *env = getenv("FLOWMPM_DRIFT_DIVISOR")) s->drift_divisor = atoi(env);
         }
         HIP_TRY(s, hipStreamSynchronize(s->stream));
         return FLOWMPM_OK;
@@ -493,8 +496,8 @@ int flowmpm_destroy(flowmpm_sim *s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (auto &p : s->events) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
     mpm::tiled_free(s->tiled);
-    if (s->store.base) (void)hipFree(s->store.base);
-    if (s->store_alt.base) (void)hipFree(s->store_alt.base);
+    if (s->store.base[0]) (void)hipFree(s->store.base[0]);
+    if (s->store.base[1]) (void)hipFree(s->store.base[1]);
     if (s->cell) (void)hipFree(s->cell);
     if (s->mass_i) (void)hipFree(s->mass_i);
     if (s->cellf) (void)hipFree(s->cellf);
@@ -730,6 +733,12 @@ int flowmpm_get_timings(flowmpm_sim *s, flowmpm_timings *out)
     int rc = timing_collect(s);
     if (rc) return rc;
     *out = s->timings;
+    if (is_tiled(s)) {
+        mpm::RebinCtl ctl;
+        HIP_TRY(s, hipMemcpyAsync(&ctl, s->tiled.ctl, sizeof ctl, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(s, hipStreamSynchronize(s->stream));
+        out->launches[FLOWMPM_TIMING_REBINS_DONE] = ctl.rebins;
+    }
     return FLOWMPM_OK;
 }
 
@@ -739,6 +748,8 @@ int flowmpm_reset_timings(flowmpm_sim *s)
     int rc = timing_collect(s);
     if (rc) return rc;
     s->timings = flowmpm_timings{};
+    if (is_tiled(s))
+        HIP_TRY(s, hipMemsetAsync(&s->tiled.ctl->rebins, 0, sizeof(int), s->stream));
     return FLOWMPM_OK;
 }
 
@@ -808,7 +819,6 @@ int flowmpm_extract_leavers(flowmpm_sim *s, const int32_t *plane_starts, int32_t
                                   &s->mig_counters, &s->mig_lists, &s->mig_list_cap, s->stream, &new_resident, &msg);
     if (rc == 1) return fail(s, FLOWMPM_ERR_HIP, "extract_leavers: " + msg);
     if (rc == 2) return fail(s, FLOWMPM_ERR_CAPACITY, "extract_leavers: " + msg);
-    if (new_resident != s->resident) s->tiled.valid = false;
     s->resident = s->live = new_resident;
     return FLOWMPM_OK;
 }
@@ -826,8 +836,7 @@ int flowmpm_insert_arrivals(flowmpm_sim *s, const void *dev_in, int64_t count)
     int rc = launch_check(s, "insert_arrivals");
     if (rc) return rc;
     s->resident += count;
-    s->live = s->resident;
-    s->tiled.valid = false;
+    s->live = s->resident;      // arrivals sit past the binned range until the next re-bin
     return FLOWMPM_OK;
 }
 

@@ -28,9 +28,10 @@ __device__ __forceinline__ bool is_leaver(float px, int x0, int nx)
 
 // counters[0..kMaxRanks): leavers per destination; counters[kMaxRanks]: total.
 __global__ void __launch_bounds__(256)
-find_leavers_kernel(Store st, long long n, int x0, int nx, RankTable rt, int *counters,
+find_leavers_kernel(StoreSel ss, long long n, int x0, int nx, RankTable rt, int *counters,
                     int *list_slot, int *list_dest, int *list_k, long long list_cap)
 {
+    const Store st = ss.pick();
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     float px = st.slot(kPosX)[j];
@@ -45,9 +46,10 @@ find_leavers_kernel(Store st, long long n, int x0, int nx, RankTable rt, int *co
 }
 
 __global__ void __launch_bounds__(256)
-pack_leavers_kernel(Store st, const int *list_slot, const int *list_dest, const int *list_k,
+pack_leavers_kernel(StoreSel ss, const int *list_slot, const int *list_dest, const int *list_k,
                     int total, RankOffsets ro, float *__restrict__ out)
 {
+    const Store st = ss.pick();
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     long long j = list_slot[e];
@@ -67,16 +69,18 @@ find_holes_kernel(const int *list_slot, int total, long long new_n, int *counter
 }
 
 __global__ void __launch_bounds__(256)
-find_movers_kernel(Store st, long long new_n, long long n, int x0, int nx, int *counters, int *movers)
+find_movers_kernel(StoreSel ss, long long new_n, long long n, int x0, int nx, int *counters, int *movers)
 {
+    const Store st = ss.pick();
     long long j = new_n + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     if (!is_leaver(st.slot(kPosX)[j], x0, nx)) movers[atomicAdd(&counters[kMaxRanks + 2], 1)] = (int)j;
 }
 
 __global__ void __launch_bounds__(256)
-fill_holes_kernel(Store st, const int *holes, const int *movers, const int *counters)
+fill_holes_kernel(StoreSel ss, const int *holes, const int *movers, const int *counters)
 {
+    const Store st = ss.pick();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int n_holes = counters[kMaxRanks + 1];
     if (i >= n_holes) return;
@@ -86,8 +90,9 @@ fill_holes_kernel(Store st, const int *holes, const int *movers, const int *coun
 }
 
 __global__ void __launch_bounds__(256)
-unpack_records_kernel(const float *__restrict__ in, Store st, long long first_slot, long long count)
+unpack_records_kernel(const float *__restrict__ in, StoreSel ss, long long first_slot, long long count)
 {
+    const Store st = ss.pick();
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const float *r = in + i * kRecordWords;
@@ -97,7 +102,7 @@ unpack_records_kernel(const float *__restrict__ in, Store st, long long first_sl
 
 // Returns 0 ok, 1 HIP failure, 2 capacity.  One host synchronisation (to learn the
 // leaver counts) per call.
-inline int extract_leavers(Store st, long long n, const Params &P, int x0, int nx,
+inline int extract_leavers(StoreSel st, long long n, const Params &P, int x0, int nx,
                            const int32_t *plane_starts, int n_ranks, float *dev_out,
                            long long capacity_records, int64_t *counts, int **counters_io,
                            int **lists_io, long long *list_cap_io, hipStream_t stream,

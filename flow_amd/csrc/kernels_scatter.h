@@ -17,6 +17,18 @@ struct Store {
     __device__ __host__ __forceinline__ int *ids() const { return reinterpret_cast<int *>(slot(kId)); }
 };
 
+// The two particle stores of a handle and the device word that says which one is current.
+// Re-binning gathers the current store into the other one and flips the word on the device, so
+// the host can enqueue steps without knowing whether a re-bin took place.  cur == nullptr:
+// a handle with a single store (the scatter algorithm).
+struct StoreSel {
+    float *base[2];
+    long long capacity;
+    const int *cur;
+    __device__ __forceinline__ Store pick() const { return Store{(cur && *cur) ? base[1] : base[0], capacity}; }
+    __device__ __forceinline__ Store other() const { return Store{(cur && *cur) ? base[0] : base[1], capacity}; }
+};
+
 // The fixed-point grid (cellBuffer, SIM:131-138) as the device holds it: momentum in 16-byte
 // records {x, y, z, unused} and the mass words in an array of their own, so that the mass
 // pass of the tiled algorithm flushes contiguous 4-byte atomics (a 64-byte memory-side atomic
@@ -53,8 +65,9 @@ clear_grid_kernel(int4 *__restrict__ cell, int *__restrict__ mass, float4 *__res
 
 // SIM:295-333.
 __global__ void __launch_bounds__(256)
-p2g1_scatter_kernel(Store st, long long n, FixedGrid g, Params P)
+p2g1_scatter_kernel(StoreSel ss, long long n, FixedGrid g, Params P)
 {
+    const Store st = ss.pick();
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
@@ -89,8 +102,9 @@ p2g1_scatter_kernel(Store st, long long n, FixedGrid g, Params P)
 
 // SIM:336-392.
 __global__ void __launch_bounds__(256)
-p2g2_scatter_kernel(Store st, long long n, FixedGrid g, Params P)
+p2g2_scatter_kernel(StoreSel ss, long long n, FixedGrid g, Params P)
 {
+    const Store st = ss.pick();
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
@@ -169,9 +183,10 @@ update_grid_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass_i
 // path (every mode uniform zero, M unused); MODES = true adds the mode branches.
 template <bool MODES>
 __global__ void __launch_bounds__(256)
-g2p_gather_kernel(Store st, long long n, const float4 *__restrict__ cellf, Params P,
+g2p_gather_kernel(StoreSel ss, long long n, const float4 *__restrict__ cellf, Params P,
                   const ModeParams *__restrict__ M)
 {
+    const Store st = ss.pick();
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     G2PIn in;
@@ -218,9 +233,10 @@ g2p_gather_kernel(Store st, long long n, const float4 *__restrict__ cellf, Param
 
 // Host AoS record (28 floats, the reference's layout) <-> SoA store.
 __global__ void __launch_bounds__(256)
-aos_to_soa_kernel(const float *__restrict__ aos, const int *__restrict__ ids, Store st,
+aos_to_soa_kernel(const float *__restrict__ aos, const int *__restrict__ ids, StoreSel ss,
                   long long first_slot, long long count)
 {
+    const Store st = ss.pick();
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const float *r = aos + i * 28;
@@ -241,9 +257,10 @@ aos_to_soa_kernel(const float *__restrict__ aos, const int *__restrict__ ids, St
 // dst_by_id != 0: record of the particle in slot j goes to row ids[j] (id order);
 // otherwise to row j, and ids_out[j] receives its id.
 __global__ void __launch_bounds__(256)
-soa_to_aos_kernel(Store st, long long count, float *__restrict__ aos, int *__restrict__ ids_out,
+soa_to_aos_kernel(StoreSel ss, long long count, float *__restrict__ aos, int *__restrict__ ids_out,
                   int dst_by_id)
 {
+    const Store st = ss.pick();
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     int id = st.ids()[j];
@@ -267,8 +284,9 @@ soa_to_aos_kernel(Store st, long long count, float *__restrict__ aos, int *__res
 
 // One per-particle field in id order (what a renderer binds).
 __global__ void __launch_bounds__(256)
-gather_field_kernel(Store st, long long count, int first_slot, int width, float *__restrict__ out)
+gather_field_kernel(StoreSel ss, long long count, int first_slot, int width, float *__restrict__ out)
 {
+    const Store st = ss.pick();
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     long long id = st.ids()[j];

@@ -71,9 +71,23 @@ struct Stragglers {
     int *list;      // slot indices, capacity = store capacity
 };
 
+// Re-binning control words, on the device.  The decision to re-bin is taken there, from the
+// number of particles that sit outside their bin's arena, so that the host can enqueue any
+// number of steps ahead and a burst of fast particles still triggers a re-bin at once.
+struct RebinCtl {
+    int cur;         // which of the two stores is current (StoreSel::cur points here)
+    int ticket;      // workgroups of the running binning kernel that have finished
+    int age;         // g2p stages since the last re-bin
+    int cum_drift;   // sum over those stages of the particles left outside their arena
+    int binned;      // particles [0, binned) are covered by the work items
+    int rebins;      // re-bins performed since the counter was last cleared
+    int pad[2];
+};
+
 struct TiledState {
-    bool valid = false;
-    int steps_since_rebin = 0;
+    bool valid = false;          // false: the next decision is forced to "re-bin"
+    bool checked = false;        // the decision for the current step has been enqueued
+    RebinCtl *ctl = nullptr;     // device
     int tiles_x = 0, tiles_y = 0, tiles_z = 0, n_tiles = 0;
     long long item_cap = 0;
     int *key = nullptr;          // per slot: tile id
@@ -87,6 +101,17 @@ struct TiledState {
 
 struct TileDims { int tiles_x, tiles_y, tiles_z; };
 
+// What a tiled particle kernel needs to find its particles.
+struct TiledWork {
+    StoreSel store;
+    const int4 *items;
+    const int *n_items;
+    RebinCtl *ctl;
+    int n;                       // live particles: items are clipped to [0, n)
+    TileDims td;
+    Stragglers sg;
+};
+
 __device__ __forceinline__ int tile_of(float px, float py, float pz, const Params &P, TileDims td)
 {
     int lx = f32_to_i32(px) - P.x_off, y = f32_to_i32(py), z = f32_to_i32(pz);
@@ -97,95 +122,149 @@ __device__ __forceinline__ int tile_of(float px, float py, float pz, const Param
 }
 
 // ---- binning -------------------------------------------------------------------
+//
+// Every step starts with two launches, bin_count_scan_kernel and bin_scatter_kernel.  Each
+// workgroup of either evaluates rebin_due() first -- a pure function of control words that
+// only the last workgroup of the second kernel changes -- and returns at once when no
+// re-bin is due, so a step without one costs two empty launches.
 
-// Pass 1: tile id per particle and its arrival rank inside the tile.  Lanes of a
-// wave that hold the same tile in a row (the common case: the store is nearly
-// sorted already) share ONE atomic on the tile counter.
-__global__ void __launch_bounds__(256)
-bin_count_kernel(Store st, long long n, Params P, TileDims td, int *__restrict__ key,
-                 int *__restrict__ rank, int *__restrict__ tile_count)
+// Whether this step starts with a re-bin: when the host asks for it (new particles), when the
+// binning is `interval` steps old, or when the particles outside their arenas -- summed over
+// the steps since the last re-bin, plus those the work items do not cover -- outweigh a
+// re-bin (each such particle costs global atomics in every stage of every step; a re-bin
+// costs about what n / divisor of them do).  divisor == 0 switches that rule off.
+__device__ __forceinline__ bool rebin_due(const RebinCtl *ctl, int n, int interval, int force, int divisor)
 {
-    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool valid = j < n;
-    int k = -1 - lane;   // distinct for idle lanes, never equal to a tile id
-    if (valid) k = tile_of(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j], P, td);
-    int prev = __shfl_up(k, 1);
-    bool head = (lane == 0) || (k != prev);
-    unsigned long long heads = __ballot(head);
-    unsigned long long upto = (2ULL << lane) - 1ULL;            // bits 0..lane
-    int start = 63 - __clzll((long long)(heads & upto));
-    unsigned long long above = heads & ~upto;
-    int end = above ? (__ffsll((long long)above) - 1) : 64;
-    int base = 0;
-    if (head && valid) base = atomicAdd(&tile_count[k], end - start);
-    base = __shfl(base, start);
-    if (valid) { key[j] = k; rank[j] = base + (lane - start); }
+    const int tail = n - min(ctl->binned, n);
+    const long long outside = (long long)ctl->cum_drift + tail;
+    return force || ctl->age >= interval || (divisor > 0 && outside * divisor > n);
 }
 
-// Pass 2 (one workgroup): exclusive scan of the tile counts into tile_start and
-// the list of work items (runs of at most kChunk particles of one tile).
-__global__ void __launch_bounds__(1024)
-bin_scan_kernel(const int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
-                int4 *__restrict__ items, int *__restrict__ n_items_out, long long item_cap)
+// True in exactly one workgroup of the launch: the one that finishes last.  Everything the
+// other workgroups wrote before their call is visible to it afterwards.
+__device__ __forceinline__ bool last_workgroup(int *ticket)
 {
-    __shared__ int s_cnt[1024];
-    __shared__ int s_itm[1024];
-    __shared__ int carry_cnt, carry_itm;
-    const int t = threadIdx.x;
-    if (t == 0) { carry_cnt = 0; carry_itm = 0; }
+    __shared__ bool last;
     __syncthreads();
-    for (int base = 0; base < n_tiles; base += 1024) {
-        int i = base + t;
-        int c = (i < n_tiles) ? tile_count[i] : 0;
-        int m = (c + kChunk - 1) / kChunk;
-        s_cnt[t] = c; s_itm[t] = m;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {       // Hillis-Steele inclusive scan
-            int a = 0, b = 0;
-            if (t >= off) { a = s_cnt[t - off]; b = s_itm[t - off]; }
-            __syncthreads();
-            s_cnt[t] += a; s_itm[t] += b;
-            __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+        if (last) *ticket = 0;
+    }
+    __syncthreads();
+    if (last) __threadfence();
+    return last;
+}
+
+// Exclusive scan of the tile counts into tile_start plus the list of work items (runs of at
+// most kChunk particles of one tile), by one workgroup of 256 threads; leaves the counts zero
+// for the next re-bin.  The counts were produced by device-scope atomics of other workgroups
+// of the same launch, hence the device-scope loads.
+__device__ __forceinline__ void scan_tiles(int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
+                                           int4 *__restrict__ items, int *__restrict__ n_items_out,
+                                           long long item_cap)
+{
+    __shared__ int wave_cnt[4], wave_itm[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int carry_cnt = 0, carry_itm = 0;
+    for (int base = 0; base < n_tiles; base += 4 * 256) {
+        const int i0 = base + 4 * t;
+        int c[4], m[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            c[q] = (i0 + q < n_tiles)
+                       ? __hip_atomic_load(&tile_count[i0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            m[q] = (c[q] + kChunk - 1) / kChunk;
         }
-        int start = carry_cnt + s_cnt[t] - c;
-        int first_item = carry_itm + s_itm[t] - m;
-        if (i < n_tiles) {
-            tile_start[i] = start;
-            for (int q = 0; q < m; q++) {
-                if (first_item + q < item_cap)
-                    items[first_item + q] = make_int4(i, start + q * kChunk, min(start + (q + 1) * kChunk, start + c), 0);
+        const int my_cnt = (c[0] + c[1]) + (c[2] + c[3]), my_itm = (m[0] + m[1]) + (m[2] + m[3]);
+        int inc_cnt = my_cnt, inc_itm = my_itm;            // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int a = __shfl_up(inc_cnt, off), b = __shfl_up(inc_itm, off);
+            if (lane >= off) { inc_cnt += a; inc_itm += b; }
+        }
+        if (lane == 63) { wave_cnt[wave] = inc_cnt; wave_itm[wave] = inc_itm; }
+        __syncthreads();
+        int start = carry_cnt + inc_cnt - my_cnt, first_item = carry_itm + inc_itm - my_itm;
+        for (int v = 0; v < wave; v++) { start += wave_cnt[v]; first_item += wave_itm[v]; }
+        const int chunk_cnt = (wave_cnt[0] + wave_cnt[1]) + (wave_cnt[2] + wave_cnt[3]);
+        const int chunk_itm = (wave_itm[0] + wave_itm[1]) + (wave_itm[2] + wave_itm[3]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = i0 + q;
+            if (i < n_tiles) {
+                tile_start[i] = start;
+                tile_count[i] = 0;
+                for (int k = 0; k < m[q]; k++)
+                    if (first_item + k < item_cap)
+                        items[first_item + k] =
+                            make_int4(i, start + k * kChunk, min(start + (k + 1) * kChunk, start + c[q]), 0);
+                start += c[q];
+                first_item += m[q];
             }
         }
-        __syncthreads();
-        if (t == 1023) { carry_cnt += s_cnt[t]; carry_itm += s_itm[t]; }
+        carry_cnt += chunk_cnt;
+        carry_itm += chunk_itm;
         __syncthreads();
     }
     if (t == 0) { tile_start[n_tiles] = carry_cnt; *n_items_out = carry_itm; }
 }
 
-// Pass 3: where does each destination slot come from?  4 bytes per particle are scattered
-// (source[dst] = src); the 96-byte records then move in pass 4 with coalesced writes.
+// First launch: tile id per particle and its arrival rank inside the tile, then (last
+// workgroup) the scan.  Lanes of a wave that hold the same tile in a row (the common case:
+// the store is nearly sorted already) share ONE atomic on the tile counter.
 __global__ void __launch_bounds__(256)
-bin_source_kernel(long long n, const int *__restrict__ key, const int *__restrict__ rank,
-                  const int *__restrict__ tile_start, int *__restrict__ source)
+bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict__ key, int *__restrict__ rank,
+                      int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
+                      int4 *__restrict__ items, int *__restrict__ n_items_out, long long item_cap,
+                      RebinCtl *ctl, int interval, int force, int divisor)
 {
-    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    source[tile_start[key[j]] + rank[j]] = (int)j;
+    if (!rebin_due(ctl, n, interval, force, divisor)) return;
+    const Store st = ss.pick();
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j0 = (long long)blockIdx.x * blockDim.x; j0 < n; j0 += stride) {
+        const long long j = j0 + threadIdx.x;
+        const bool valid = j < n;
+        int k = -1 - lane;   // distinct for idle lanes, never equal to a tile id
+        if (valid) k = tile_of(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j], P, td);
+        int prev = __shfl_up(k, 1);
+        bool head = (lane == 0) || (k != prev);
+        unsigned long long heads = __ballot(head);
+        unsigned long long upto = (2ULL << lane) - 1ULL;            // bits 0..lane
+        int start = 63 - __clzll((long long)(heads & upto));
+        unsigned long long above = heads & ~upto;
+        int end = above ? (__ffsll((long long)above) - 1) : 64;
+        int base = 0;
+        if (head && valid) base = atomicAdd(&tile_count[k], end - start);
+        base = __shfl(base, start);
+        if (valid) { key[j] = k; rank[j] = base + (lane - start); }
+    }
+    if (last_workgroup(&ctl->ticket)) scan_tiles(tile_count, n_tiles, tile_start, items, n_items_out, item_cap);
 }
 
-// Pass 4: gather every record into its slot of the binned store.  Writes are perfectly
-// coalesced; reads follow `source`, which is close to the identity because the store was
-// binned a few steps ago, so they coalesce almost as well.
+// Second launch: every record moves to its slot of the other store (reads coalesced; writes
+// nearly so, because the store was binned a few steps ago), then (last workgroup) the other
+// store becomes current.
 __global__ void __launch_bounds__(256)
-bin_gather_kernel(Store src, Store dst, long long n, const int *__restrict__ source)
+bin_scatter_kernel(StoreSel ss, int n, const int *__restrict__ key, const int *__restrict__ rank,
+                   const int *__restrict__ tile_start, RebinCtl *ctl, int interval, int force, int divisor)
 {
-    long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= n) return;
-    long long j = source[d];
+    if (!rebin_due(ctl, n, interval, force, divisor)) return;
+    const Store src = ss.pick(), dst = ss.other();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const int d = tile_start[key[j]] + rank[j];
 #pragma unroll
-    for (int w = 0; w < kRecordWords; w++) dst.slot(w)[d] = src.slot(w)[j];
+        for (int w = 0; w < kRecordWords; w++) dst.slot(w)[d] = src.slot(w)[j];
+    }
+    if (last_workgroup(&ctl->ticket) && threadIdx.x == 0) {
+        ctl->cur ^= 1;
+        ctl->age = 0;
+        ctl->cum_drift = 0;
+        ctl->binned = n;
+        ctl->rebins += 1;
+    }
 }
 
 // ---- arena helpers ---------------------------------------------------------------
@@ -254,6 +333,16 @@ __device__ __forceinline__ int item_for_block(int n_items)
 #endif
 }
 
+// The work item of this workgroup, clipped to the live particles; false when there is none.
+__device__ __forceinline__ bool take_item(const TiledWork &w, int4 *item)
+{
+    const int id = item_for_block(*w.n_items);
+    if (id < 0) return false;
+    *item = w.items[id];
+    item->z = min(item->z, w.n);
+    return item->y < item->z;
+}
+
 // ---- p2g1 (SIM:295-333) ------------------------------------------------------------
 
 // One particle's 27 x 4 contributions.  INSIDE: the whole stencil lies in the
@@ -308,14 +397,14 @@ __device__ __forceinline__ bool stencil_in_arena(const Stencil &s, const Arena &
 }
 
 __global__ void __launch_bounds__(kTiledThreads)
-p2g1_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                  TileDims td, FixedGrid g, Params P, Stragglers sg)
+p2g1_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
-    const int item_id = item_for_block(*n_items);
-    if (item_id < 0) return;
+    const Store st = w.store.pick();
+    int4 item;
+    if (!take_item(w, &item)) return;
+    const Stragglers sg = w.sg;
     __shared__ int lds[4 * kArenaPad];
-    const int4 item = items[item_id];
-    const Arena A = arena_of_tile(item.x, td, P);
+    const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < 4 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     __syncthreads();
 
@@ -396,15 +485,15 @@ __device__ __forceinline__ void p2g2_particle(const Stencil &s, const float C[9]
 }
 
 __global__ void __launch_bounds__(kTiledThreads)
-p2g2_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                  TileDims td, FixedGrid g, Params P, Stragglers sg)
+p2g2_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
-    const int item_id = item_for_block(*n_items);
-    if (item_id < 0) return;
+    const Store st = w.store.pick();
+    int4 item;
+    if (!take_item(w, &item)) return;
+    const Stragglers sg = w.sg;
     __shared__ int lds[3 * kArenaPad];
     __shared__ float mass_f[kArenaCells];      // decodeFixedPoint(cell.mass), once per arena cell
-    const int4 item = items[item_id];
-    const Arena A = arena_of_tile(item.x, td, P);
+    const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
         long long c = arena_cell_to_grid(a, A, P);
@@ -468,14 +557,14 @@ __device__ __forceinline__ void p2g_mass_particle(const Stencil &s, int *lds, in
 }
 
 __global__ void __launch_bounds__(kTiledThreads)
-p2g_mass_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                      TileDims td, FixedGrid g, Params P, Stragglers sg)
+p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
-    const int item_id = item_for_block(*n_items);
-    if (item_id < 0) return;
+    const Store st = w.store.pick();
+    int4 item;
+    if (!take_item(w, &item)) return;
+    const Stragglers sg = w.sg;
     __shared__ int lds[kArenaCells];
-    const int4 item = items[item_id];
-    const Arena A = arena_of_tile(item.x, td, P);
+    const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < kArenaCells; i += kTiledThreads) lds[i] = 0;
     __syncthreads();
     for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
@@ -562,15 +651,15 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
 }
 
 __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_P2G_WAVES)
-p2g_momentum_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                          TileDims td, FixedGrid g, Params P, Stragglers sg)
+p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
-    const int item_id = item_for_block(*n_items);
-    if (item_id < 0) return;
+    const Store st = w.store.pick();
+    int4 item;
+    if (!take_item(w, &item)) return;
+    const Stragglers sg = w.sg;
     __shared__ int lds[3 * kArenaPad];
     __shared__ float mass_f[kArenaCells];
-    const int4 item = items[item_id];
-    const Arena A = arena_of_tile(item.x, td, P);
+    const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
         long long c = arena_cell_to_grid(a, A, P);
@@ -660,15 +749,15 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
 
 template <bool MODES>
 __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_G2P_WAVES)
-g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                 TileDims td, const float4 *__restrict__ cellf, Params P, Stragglers sg,
+g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
                  const ModeParams *__restrict__ M)
 {
-    const int item_id = item_for_block(*n_items);
-    if (item_id < 0) return;
+    const Store st = w.store.pick();
+    int4 item;
+    if (!take_item(w, &item)) return;
+    const Stragglers sg = w.sg;
     __shared__ float4 grid[kArenaCells];
-    const int4 item = items[item_id];
-    const Arena A = arena_of_tile(item.x, td, P);
+    const Arena A = arena_of_tile(item.x, w.td, P);
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
         long long c = arena_cell_to_grid(a, A, P);
         grid[a] = (c >= 0) ? cellf[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -684,6 +773,7 @@ g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict
         r.mass = st.slot(kMass)[q];
         r.dirx = st.slot(kDirX)[q]; r.diry = st.slot(kDirY)[q]; r.dirz = st.slot(kDirZ)[q];
     };
+    int drifted = 0;    // particles this thread leaves outside the arena: stragglers of the next step
     if (j < item.z) load(in, j);
     while (j < item.z) {
         const int jn = j + kTiledThreads;
@@ -715,6 +805,10 @@ g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict
             st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;
             st.slot(kVelX)[j] = o.vx; st.slot(kVelY)[j] = o.vy; st.slot(kVelZ)[j] = o.vz;
             st.slot(kDirX)[j] = o.dirx; st.slot(kDirY)[j] = o.diry; st.slot(kDirZ)[j] = o.dirz;
+            const int bx = f32_to_i32(o.px) - 1 - A.ox, by = f32_to_i32(o.py) - 1 - A.oy,
+                      bz = f32_to_i32(o.pz) - 1 - A.oz;
+            drifted += !((unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
+                         (unsigned)bz <= (unsigned)(kAZ - 3));
         } else {
             add_straggler(sg, j);
         }
@@ -725,18 +819,34 @@ g2p_tiled_kernel(Store st, const int4 *__restrict__ items, const int *__restrict
 #endif
         j = jn;
     }
+    if (__any(drifted != 0)) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) drifted += __shfl_down(drifted, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&w.ctl->cum_drift, drifted);
+    }
 }
 
 // ---- stragglers --------------------------------------------------------------------
-// One thread per listed particle, contributions straight to / from the global grids
-// (the reference's own access pattern).  PASS: 0 p2g1, 1 p2g2, 2 mass pass, 3 momentum pass.
+// One thread per particle the tiled kernel did not handle -- those it listed, and the live
+// particles past the binned range (arrivals from other slabs since the last re-bin) -- with
+// contributions straight to / from the global grids (the reference's own access pattern).
+// PASS: 0 p2g1, 1 p2g2, 2 mass pass, 3 momentum pass.
+__device__ __forceinline__ int straggler_total(const TiledWork &w, int *count, int *tail_begin)
+{
+    *count = *w.sg.count;
+    *tail_begin = min(w.ctl->binned, w.n);
+    return *count + (w.n - *tail_begin);
+}
+
 template <int PASS>
 __global__ void __launch_bounds__(256)
-straggler_p2g_kernel(Store st, Stragglers sg, FixedGrid g, Params P)
+straggler_p2g_kernel(TiledWork w, FixedGrid g, Params P)
 {
-    const int count = *sg.count;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const int j = sg.list[i];
+    const Store st = w.store.pick();
+    int count, tail_begin;
+    const int total = straggler_total(w, &count, &tail_begin);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i < count ? w.sg.list[i] : tail_begin + (i - count);
         float in[15];
 #pragma unroll
         for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
@@ -752,12 +862,19 @@ straggler_p2g_kernel(Store st, Stragglers sg, FixedGrid g, Params P)
 
 template <bool MODES>
 __global__ void __launch_bounds__(256)
-straggler_g2p_kernel(Store st, Stragglers sg, const float4 *__restrict__ cellf, Params P,
+straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
                      const ModeParams *__restrict__ M)
 {
-    const int count = *sg.count;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const int j = sg.list[i];
+    const Store st = w.store.pick();
+    int count, tail_begin;
+    const int total = straggler_total(w, &count, &tail_begin);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // bookkeeping of the step that ends here: every particle on this path counts as outside
+        if (total) atomicAdd(&w.ctl->cum_drift, total);
+        w.ctl->age += 1;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i < count ? w.sg.list[i] : tail_begin + (i - count);
         G2PIn in;
         in.px = st.slot(kPosX)[j]; in.py = st.slot(kPosY)[j]; in.pz = st.slot(kPosZ)[j];
         in.mass = st.slot(kMass)[j];
@@ -801,14 +918,17 @@ inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStr
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.key), (size_t)capacity * sizeof(int)), "hipMalloc key")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.rank), (size_t)capacity * sizeof(int)), "hipMalloc rank")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.tile_count), (size_t)T.n_tiles * sizeof(int)), "hipMalloc tile_count")) return 1;
+    if (chk(e = hipMemsetAsync(T.tile_count, 0, (size_t)T.n_tiles * sizeof(int), stream), "memset tile_count")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.tile_start), (size_t)(T.n_tiles + 1) * sizeof(int)), "hipMalloc tile_start")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.items), (size_t)T.item_cap * sizeof(int4)), "hipMalloc items")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.n_items), sizeof(int)), "hipMalloc n_items")) return 1;
     if (chk(e = hipMemsetAsync(T.n_items, 0, sizeof(int), stream), "memset n_items")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.stragglers.count), 256), "hipMalloc straggler count")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.stragglers.list), (size_t)capacity * sizeof(int)), "hipMalloc straggler list")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.ctl), sizeof(RebinCtl)), "hipMalloc rebin control")) return 1;
+    if (chk(e = hipMemsetAsync(T.ctl, 0, sizeof(RebinCtl), stream), "memset rebin control")) return 1;
     T.valid = false;
-    T.steps_since_rebin = 0;
+    T.checked = false;
     return 0;
 }
 
@@ -822,30 +942,37 @@ inline void tiled_free(TiledState &T)
     if (T.n_items) (void)hipFree(T.n_items);
     if (T.stragglers.count) (void)hipFree(T.stragglers.count);
     if (T.stragglers.list) (void)hipFree(T.stragglers.list);
+    if (T.ctl) (void)hipFree(T.ctl);
     T = TiledState{};
 }
 
-// Groups the first n particles of `src` by tile into `dst` and rebuilds the work items.
-inline int rebin(TiledState &T, Store src, Store dst, long long n, const Params &P, hipStream_t stream,
-                 std::string *msg)
+// Blocks of the grid-stride binning kernels: enough to fill the chip, few enough that a
+// launch which finds no re-bin due costs next to nothing.
+constexpr unsigned kBinBlocks = 2048;
+
+// Enqueues the start-of-step pair of launches (see "binning" above).  When a re-bin is due the
+// first n particles of the current store are grouped by tile into the other store, the work
+// items are rebuilt and the other store becomes current.
+inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P, int interval, int divisor,
+                        hipStream_t stream, std::string *msg)
 {
-    hipError_t e = hipMemsetAsync(T.tile_count, 0, (size_t)T.n_tiles * sizeof(int), stream);
-    if (e != hipSuccess) { *msg = std::string("memset tile_count: ") + hipGetErrorString(e); return 1; }
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    const TileDims td = tile_dims(T);
-    hipLaunchKernelGGL(bin_count_kernel, dim3(blocks), dim3(256), 0, stream, src, n, P, td, T.key, T.rank, T.tile_count);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, stream, T.tile_count, T.n_tiles, T.tile_start,
-                       T.items, T.n_items, T.item_cap);
-    // `key` is dead once `source` is built, but both are read/written in pass 3, so the
-    // straggler list (unused during a re-bin) lends its storage for `source`.
-    int *source = T.stragglers.list;
-    hipLaunchKernelGGL(bin_source_kernel, dim3(blocks), dim3(256), 0, stream, n, T.key, T.rank, T.tile_start, source);
-    hipLaunchKernelGGL(bin_gather_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n, source);
-    e = hipGetLastError();
+    const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, kBinBlocks);
+    const int force = T.valid ? 0 : 1;
+    hipLaunchKernelGGL(bin_count_scan_kernel, dim3(blocks), dim3(256), 0, stream, ss, (int)n, P, tile_dims(T), T.key,
+                       T.rank, T.tile_count, T.n_tiles, T.tile_start, T.items, T.n_items, T.item_cap, T.ctl,
+                       interval, force, divisor);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, stream, ss, (int)n, T.key, T.rank,
+                       T.tile_start, T.ctl, interval, force, divisor);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) { *msg = std::string("rebin launch: ") + hipGetErrorString(e); return 1; }
     T.valid = true;
-    T.steps_since_rebin = 0;
+    T.checked = true;
     return 0;
+}
+
+inline TiledWork tiled_work(const TiledState &T, StoreSel ss, long long n)
+{
+    return TiledWork{ss, T.items, T.n_items, T.ctl, (int)n, tile_dims(T), T.stragglers};
 }
 
 // Upper bound of the work items any binning of n particles can produce.
@@ -856,55 +983,53 @@ inline unsigned item_bound(const TiledState &T, long long n)
 }
 
 // Every tiled stage is: zero the straggler counter, the tiled kernel, the straggler kernel.
-constexpr int kStragglerBlocks = 128;
+constexpr int kStragglerBlocks = 1024;
 
 #define FLOWMPM_TILED_STAGE(kernel, straggler_kernel, grid_ptr)                                              \
     do {                                                                                                    \
         if (hipMemsetAsync(T.stragglers.count, 0, sizeof(int), stream) != hipSuccess) return 1;             \
-        hipLaunchKernelGGL(kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, st, T.items,     \
-                           T.n_items, tile_dims(T), grid_ptr, P, T.stragglers);                             \
-        hipLaunchKernelGGL(straggler_kernel, dim3(kStragglerBlocks), dim3(256), 0, stream, st, T.stragglers, \
-                           grid_ptr, P);                                                                    \
+        const TiledWork w = tiled_work(T, st, n);                                                           \
+        hipLaunchKernelGGL(kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, w, grid_ptr, P); \
+        hipLaunchKernelGGL(straggler_kernel, dim3(kStragglerBlocks), dim3(256), 0, stream, w, grid_ptr, P); \
         return 0;                                                                                           \
     } while (0)
 
-inline int launch_p2g1_tiled(TiledState &T, Store st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
+inline int launch_p2g1_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
 {
     FLOWMPM_TILED_STAGE(p2g1_tiled_kernel, straggler_p2g_kernel<0>, g);
 }
 
-inline int launch_p2g2_tiled(TiledState &T, Store st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
+inline int launch_p2g2_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
 {
     FLOWMPM_TILED_STAGE(p2g2_tiled_kernel, straggler_p2g_kernel<1>, g);
 }
 
-inline int launch_p2g_mass_tiled(TiledState &T, Store st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
+inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
 {
     FLOWMPM_TILED_STAGE(p2g_mass_tiled_kernel, straggler_p2g_kernel<2>, g);
 }
 
-inline int launch_p2g_momentum_tiled(TiledState &T, Store st, long long n, FixedGrid g, const Params &P,
+inline int launch_p2g_momentum_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P,
                                      hipStream_t stream)
 {
     FLOWMPM_TILED_STAGE(p2g_momentum_tiled_kernel, straggler_p2g_kernel<3>, g);
 }
 
 // modes == nullptr: chaos path.
-inline int launch_g2p_tiled(TiledState &T, Store st, long long n, const float4 *cellf, const Params &P,
+inline int launch_g2p_tiled(TiledState &T, StoreSel st, long long n, const float4 *cellf, const Params &P,
                             const ModeParams *modes, hipStream_t stream)
 {
     if (hipMemsetAsync(T.stragglers.count, 0, sizeof(int), stream) != hipSuccess) return 1;
     const dim3 grid(item_bound(T, n)), block(kTiledThreads);
+    const TiledWork w = tiled_work(T, st, n);
     if (modes) {
-        hipLaunchKernelGGL(g2p_tiled_kernel<true>, grid, block, 0, stream, st, T.items, T.n_items, tile_dims(T),
-                           cellf, P, T.stragglers, modes);
-        hipLaunchKernelGGL(straggler_g2p_kernel<true>, dim3(kStragglerBlocks), dim3(256), 0, stream, st,
-                           T.stragglers, cellf, P, modes);
+        hipLaunchKernelGGL(g2p_tiled_kernel<true>, grid, block, 0, stream, w, cellf, P, modes);
+        hipLaunchKernelGGL(straggler_g2p_kernel<true>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, cellf, P,
+                           modes);
     } else {
-        hipLaunchKernelGGL(g2p_tiled_kernel<false>, grid, block, 0, stream, st, T.items, T.n_items, tile_dims(T),
-                           cellf, P, T.stragglers, modes);
-        hipLaunchKernelGGL(straggler_g2p_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, st,
-                           T.stragglers, cellf, P, modes);
+        hipLaunchKernelGGL(g2p_tiled_kernel<false>, grid, block, 0, stream, w, cellf, P, modes);
+        hipLaunchKernelGGL(straggler_g2p_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, cellf, P,
+                           modes);
     }
     return 0;
 }

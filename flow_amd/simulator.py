@@ -157,7 +157,9 @@ class Handle:
         t = _lib.Timings()
         self._chk(self.L.flowmpm_get_timings(self._h, ctypes.byref(t)))
         names = list(_lib.KERNEL_NAMES) + ["rebin"]
-        return {names[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(len(names))}
+        out = {names[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(len(names))}
+        out["rebin"]["performed"] = t.launches[_lib.TIMING_REBINS_DONE]
+        return out
 
     # ---- slab decomposition ----
     def plane_bytes(self):
@@ -241,7 +243,7 @@ class _Uniforms:
 class MlsMpmSimulator:
     fixedPointMultiplier = 1e7          # SIM:43
 
-    def __init__(self, renderer=None, conf=None, device=0, algorithm=_lib.ALGO_TILED, rebin_interval=4,
+    def __init__(self, renderer=None, conf=None, device=0, algorithm=_lib.ALGO_TILED, rebin_interval=64,
                  seed=0xF10E5EED, clock=None):
         self.clock = clock               # stands in for Date.now(), milliseconds (SIM:1827, 2428)
         self.renderer = renderer         # kept for signature parity; unused (SIM:71-73)

@@ -28,7 +28,7 @@ class MlsMpmSimulator {
         this.conf = o.conf || defaultConf;
         this.seed = o.seed === undefined ? 0xF10E5EED : o.seed;
         this.device = o.device || 0;
-        this.rebinInterval = o.rebinInterval || 1;
+        this.rebinInterval = o.rebinInterval || 64;
         this.algorithm = o.algorithm === undefined ? 1 : o.algorithm;
         this.numParticles = 0;
         this.gridSize = new Vector3(0, 0, 0);

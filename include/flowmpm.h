@@ -51,7 +51,8 @@ extern "C" {
 
 /* Timing slots reported by flowmpm_get_timings: the five kernels, then the
  * particle re-binning pass of the tiled algorithm (no reference counterpart). */
-#define FLOWMPM_TIMING_REBIN        5
+#define FLOWMPM_TIMING_REBIN        5   /* the start-of-step re-binning sequence (runs every step; most return at once) */
+#define FLOWMPM_TIMING_REBINS_DONE  6   /* launches[] only: re-bins the device actually performed */
 #define FLOWMPM_TIMING_SLOTS        8
 
 /* How the particle-to-grid scatter is organised. */
@@ -94,7 +95,9 @@ typedef struct {
                                          whole grid (single GPU) */
     int32_t device;                   /* HIP device ordinal */
     int32_t algorithm;                /* FLOWMPM_ALGO_* */
-    int32_t rebin_interval;           /* tiled: re-bin particles every k steps (>= 1) */
+    int32_t rebin_interval;           /* tiled: re-bin particles at least every k steps (>= 1); the
+                                       * device re-bins earlier when too many particles have left
+                                       * their tile's neighbourhood.  Never affects results. */
     int64_t max_particles;            /* conf.maxParticles, src/conf.js:8 */
     void   *stream;                   /* hipStream_t to enqueue on when external_stream != 0
                                          (NULL is then the device's default stream) */
