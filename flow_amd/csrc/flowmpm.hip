@@ -37,7 +37,8 @@ struct flowmpm_sim {
     flowmpm_uniforms uniforms{};
     flowmpm_mode_uniforms modes{};
     mpm::ModeParams *d_modes = nullptr;   // device copy g2p's mode instantiation reads
-    bool modes_stale = true;              // d_modes differs from `modes` / the two mode flags
+    bool modes_stale = true;              // d_modes differs from `modes` / the mode flags of `uniforms`
+    long long modes_for_live = -1;        // numParticles held by d_modes
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool slab = false;
@@ -257,7 +258,8 @@ int stage_update_grid(flowmpm_sim *s)
 bool any_mode_on(const flowmpm_sim *s)
 {
     const flowmpm_mode_uniforms &m = s->modes;
-    bool on = s->uniforms.grid_mode != 0 || s->uniforms.front_gravity_mode != 0 || m.cylinder_mode != 0 ||
+    bool on = s->uniforms.grid_mode != 0 || s->uniforms.front_gravity_mode != 0 ||
+              s->uniforms.hide_percentage > 0.0f || m.cylinder_mode != 0 ||
               m.sphere_containment_mode != 0 || m.polygon_containment_mode != 0 || m.color_spheres_mode != 0 ||
               m.two_color_sphere_mode != 0;
     for (int k = 0; k < FLOWMPM_SEGMENTS; k++) on = on || m.segment_mode[k] != 0;
@@ -279,11 +281,14 @@ int stage_g2p(flowmpm_sim *s)
     if (is_tiled(s) && (rc = stage_rebin_if_needed(s))) return rc;
     const mpm::ModeParams *modes = nullptr;
     if (any_mode_on(s)) {
-        if (s->modes_stale) {
+        if (s->modes_stale || s->modes_for_live != s->live) {
             mpm::ModeParams value;
             value.u = s->modes;
             value.grid_mode = s->uniforms.grid_mode;
             value.front_gravity_mode = s->uniforms.front_gravity_mode;
+            value.hide_percentage = s->uniforms.hide_percentage;
+            value.num_particles = (unsigned)s->live;      // uniforms.numParticles (SIM:2513-2522)
+            s->modes_for_live = s->live;
             hipLaunchKernelGGL(store_modes_kernel, dim3(1), dim3(256), 0, s->stream, value, s->d_modes);
             if ((rc = launch_check(s, "store_modes"))) return rc;
             s->modes_stale = false;
@@ -327,8 +332,9 @@ int stage_rebin_if_needed(flowmpm_sim *s)
 
 int validate_uniforms(flowmpm_sim *s, const flowmpm_uniforms *u)
 {
-    if (u->hide_percentage != 0.0f)
-        return fail(s, FLOWMPM_ERR_UNSUPPORTED, "hidePercentage != 0 is not implemented");
+    if (u->hide_percentage > 0.0f && s->slab)
+        return fail(s, FLOWMPM_ERR_UNSUPPORTED,
+                    "hidePercentage > 0 on a slab handle (it needs the particle count of the whole domain)");
     if (u->cursor_interaction > 1u)
         return fail(s, FLOWMPM_ERR_INVALID, "cursorInteraction must be 0 or 1");
     return FLOWMPM_OK;
@@ -539,7 +545,8 @@ int flowmpm_set_uniforms(flowmpm_sim *s, const flowmpm_uniforms *u)
     if (!s || !u) return fail(s, FLOWMPM_ERR_INVALID, "null argument");
     int rc = validate_uniforms(s, u);
     if (rc) return rc;
-    if (u->grid_mode != s->uniforms.grid_mode || u->front_gravity_mode != s->uniforms.front_gravity_mode)
+    if (u->grid_mode != s->uniforms.grid_mode || u->front_gravity_mode != s->uniforms.front_gravity_mode ||
+        u->hide_percentage != s->uniforms.hide_percentage)
         s->modes_stale = true;
     s->uniforms = *u;
     refresh_params(s);

@@ -195,16 +195,21 @@ g2p_gather_kernel(StoreSel ss, long long n, const float4 *__restrict__ cellf, Pa
     in.dirx = st.slot(kDirX)[j]; in.diry = st.slot(kDirY)[j]; in.dirz = st.slot(kDirZ)[j];
 
     Vec3 v;
-    if (MODES)
-        v = g2p_pre_forces_modes(in.px, in.py, in.pz, st.slot(kColR)[j], st.slot(kColG)[j], st.slot(kColB)[j],
-                                 st.ids()[j], P, M);
+    int index = 0;
+    bool hide = false;
+    if (MODES) {
+        index = st.ids()[j];
+        hide = mode_hidden(index, M);
+        v = g2p_pre_forces_modes(in.px, in.py, in.pz, st.slot(kColR)[j], st.slot(kColG)[j], st.slot(kColB)[j], index,
+                                 hide, P, M);
+    }
     else
         v = g2p_pre_forces(in.px, in.py, in.pz, P);
     Stencil s = make_stencil(in.px, in.py, in.pz);
     float B[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) B[k] = 0.0f;
-    const bool gather = !MODES || M->grid_mode == 0u;   // SIM:1322: no gather in grid mode
+    const bool gather = !MODES || (M->grid_mode == 0u && !hide);   // SIM:1332
 #pragma unroll
     for (int gx = 0; gx < 3 && gather; gx++)
 #pragma unroll
@@ -223,7 +228,7 @@ g2p_gather_kernel(StoreSel ss, long long n, const float4 *__restrict__ cellf, Pa
                 v.x = v.x + wvx; v.y = v.y + wvy; v.z = v.z + wvz;
             }
         }
-    G2POut o = MODES ? g2p_finish_modes(in, v, B, P, M) : g2p_finish(in, v, B, P);
+    G2POut o = MODES ? g2p_finish_modes(in, v, B, index, hide, P, M) : g2p_finish(in, v, B, P);
 #pragma unroll
     for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
     st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;

@@ -784,9 +784,14 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
         int abase;
         if (stencil_in_arena(s, A, &abase)) {
             Vec3 v;
-            if (MODES)
-                v = g2p_pre_forces_modes(in.px, in.py, in.pz, st.slot(kColR)[j], st.slot(kColG)[j],
-                                         st.slot(kColB)[j], st.ids()[j], P, M);
+            int index = 0;
+            bool hide = false;
+            if (MODES) {
+                index = st.ids()[j];
+                hide = mode_hidden(index, M);
+                v = g2p_pre_forces_modes(in.px, in.py, in.pz, st.slot(kColR)[j], st.slot(kColG)[j], st.slot(kColB)[j], index,
+                                         hide, P, M);
+            }
             else
                 v = g2p_pre_forces(in.px, in.py, in.pz, P);
 #if FLOWMPM_G2P_PHASE_BARRIERS
@@ -795,11 +800,11 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
             float B[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) B[k] = 0.0f;
-            if (!MODES || M->grid_mode == 0u) g2p_gather<true>(s, grid, abase, cellf, P, v, B);
+            if (!MODES || (M->grid_mode == 0u && !hide)) g2p_gather<true>(s, grid, abase, cellf, P, v, B);
 #if FLOWMPM_G2P_PHASE_BARRIERS
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            G2POut o = MODES ? g2p_finish_modes(in, v, B, P, M) : g2p_finish(in, v, B, P);
+            G2POut o = MODES ? g2p_finish_modes(in, v, B, index, hide, P, M) : g2p_finish(in, v, B, P);
 #pragma unroll
             for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
             st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;
@@ -880,17 +885,22 @@ straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
         in.mass = st.slot(kMass)[j];
         in.dirx = st.slot(kDirX)[j]; in.diry = st.slot(kDirY)[j]; in.dirz = st.slot(kDirZ)[j];
         Vec3 v;
-        if (MODES)
-            v = g2p_pre_forces_modes(in.px, in.py, in.pz, st.slot(kColR)[j], st.slot(kColG)[j], st.slot(kColB)[j],
-                                     st.ids()[j], P, M);
+        int index = 0;
+        bool hide = false;
+        if (MODES) {
+            index = st.ids()[j];
+            hide = mode_hidden(index, M);
+            v = g2p_pre_forces_modes(in.px, in.py, in.pz, st.slot(kColR)[j], st.slot(kColG)[j], st.slot(kColB)[j], index,
+                                     hide, P, M);
+        }
         else
             v = g2p_pre_forces(in.px, in.py, in.pz, P);
         Stencil s = make_stencil(in.px, in.py, in.pz);
         float B[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) B[k] = 0.0f;
-        if (!MODES || M->grid_mode == 0u) g2p_gather<false>(s, nullptr, 0, cellf, P, v, B);
-        G2POut o = MODES ? g2p_finish_modes(in, v, B, P, M) : g2p_finish(in, v, B, P);
+        if (!MODES || (M->grid_mode == 0u && !hide)) g2p_gather<false>(s, nullptr, 0, cellf, P, v, B);
+        G2POut o = MODES ? g2p_finish_modes(in, v, B, index, hide, P, M) : g2p_finish(in, v, B, P);
 #pragma unroll
         for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
         st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;

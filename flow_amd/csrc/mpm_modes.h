@@ -15,7 +15,17 @@ struct ModeParams {
     flowmpm_mode_uniforms u;
     unsigned grid_mode;            // uniforms.gridMode (SIM:152)
     unsigned front_gravity_mode;   // uniforms.frontGravityMode (SIM:153)
+    float hide_percentage;         // uniforms.hidePercentage (SIM:260)
+    unsigned num_particles;        // uniforms.numParticles (SIM:151)
 };
+
+// SIM:441-442: the first hidePercentage percent of the buffer are "hidden": no mode force, no
+// gather, no mouse force, parked at the x faces instead.
+__device__ __forceinline__ bool mode_hidden(int index, const ModeParams *__restrict__ M)
+{
+    const float index_percent = ((float)(unsigned)index / (float)M->num_particles) * 100.0f;
+    return M->hide_percentage > 0.0f && index_percent < M->hide_percentage;
+}
 
 // Colours the population-segment modes compare particle colours with (SIM:766, 847, 906,
 // 965, 1024, 1083, 1142, 1201, 1260), in the order of flowmpm_mode_uniforms.
@@ -75,13 +85,14 @@ __device__ __forceinline__ void repel_from_sphere(Vec3 &v, float px, float py, f
 // (SIM:444-1320).  `index` is the reference's instanceIndex: the particle's slot in the
 // host's buffer, which the store carries in its id slot.
 __device__ __forceinline__ Vec3 g2p_pre_forces_modes(float px, float py, float pz, float cr, float cg, float cb,
-                                                     int index, const Params &P, const ModeParams *__restrict__ M)
+                                                     int index, bool hide, const Params &P,
+                                                     const ModeParams *__restrict__ M)
 {
     const flowmpm_mode_uniforms &m = M->u;
     const float dt = P.dt;
     Vec3 v{0.0f, 0.0f, 0.0f};
 
-    if (M->grid_mode == 1u) {                       // SIM:445-482
+    if (M->grid_mode == 1u && !hide) {              // SIM:445-482
         const int gw = (int)m.grid_width;
         const int gxi = gw ? index % gw : 0;        // WGSL: x % 0 = 0, x / 0 = x
         const int gyi = gw ? index / gw : index;
@@ -102,7 +113,7 @@ __device__ __forceinline__ Vec3 g2p_pre_forces_modes(float px, float py, float p
         float ox = tx - px, oy = ty - py, oz = tz - pz;
         float dist = length3(ox, oy, oz);
         mode_push(v, ox / dist, oy / dist, oz / dist, dist * 10.0f, dt);
-    } else if (M->front_gravity_mode == 1u) {       // SIM:485-488
+    } else if (M->front_gravity_mode == 1u && !hide) {   // SIM:485-488
         v.x = v.x + (0.0f * 0.1f) * dt;
         v.y = v.y + (0.0f * 0.1f) * dt;
         v.z = v.z + (-1.0f * 0.1f) * dt;
@@ -114,7 +125,7 @@ __device__ __forceinline__ Vec3 g2p_pre_forces_modes(float px, float py, float p
         v.z = v.z - (pn.z * 0.1f) * dt;
     }
 
-    if (m.cylinder_mode == 1u) {                    // SIM:497-511
+    if (m.cylinder_mode == 1u && !hide) {           // SIM:497-511
         float tx = px - m.cylinder_center_x, ty = py - m.cylinder_center_y;
         float dist = length3(tx, ty, 0.0f);
         if (dist < m.cylinder_radius) {
@@ -122,12 +133,12 @@ __device__ __forceinline__ Vec3 g2p_pre_forces_modes(float px, float py, float p
             mode_push(v, tx / dist, ty / dist, 0.0f / dist, strength, dt);
         }
     }
-    if (m.sphere_containment_mode == 1u)            // SIM:514-529
+    if (m.sphere_containment_mode == 1u && !hide)   // SIM:514-529
         contain_in_sphere(v, px, py, pz, m.sphere_center, m.sphere_radius, false, 0.0f, dt);
-    if (m.two_color_sphere_mode == 1u)              // SIM:532-547
+    if (m.two_color_sphere_mode == 1u && !hide)     // SIM:532-547
         contain_in_sphere(v, px, py, pz, m.sphere_center, m.sphere_radius, false, 0.0f, dt);
 
-    if (m.polygon_containment_mode == 1u) {         // SIM:550-696
+    if (m.polygon_containment_mode == 1u && !hide) {    // SIM:550-696
         const int count = (int)m.polygon_vertex_count;
         int inside = 0;
         for (int i = 0; i < count; i++) {
@@ -164,7 +175,7 @@ __device__ __forceinline__ Vec3 g2p_pre_forces_modes(float px, float py, float p
         }
     }
 
-    if (m.color_spheres_mode == 1u) {               // SIM:699-759
+    if (m.color_spheres_mode == 1u && !hide) {      // SIM:699-759
         float min_dist = 999.0f;
         int closest = 0;
         for (int i = 0; i < 10; i++) {
@@ -177,7 +188,7 @@ __device__ __forceinline__ Vec3 g2p_pre_forces_modes(float px, float py, float p
     }
 
     for (int k = 0; k < FLOWMPM_SEGMENTS; k++) {    // SIM:762-1313
-        if (m.segment_mode[k] != 1u) continue;
+        if (m.segment_mode[k] != 1u || hide) continue;
         const bool is_segment =
             length3(cr - kSegmentColor[k][0], cg - kSegmentColor[k][1], cb - kSegmentColor[k][2]) < 0.1f;
         const float eased = eased_boost(m.segment_boost_time[k], m.segment_boost_duration[k]);
@@ -199,17 +210,17 @@ __device__ __forceinline__ Vec3 g2p_pre_forces_modes(float px, float py, float p
 }
 
 // The velocity dampings applied after C is stored (SIM:1365-1476).
-__device__ __forceinline__ Vec3 mode_damping(Vec3 v, const ModeParams *__restrict__ M)
+__device__ __forceinline__ Vec3 mode_damping(Vec3 v, bool hide, const ModeParams *__restrict__ M)
 {
     const flowmpm_mode_uniforms &m = M->u;
     if (M->front_gravity_mode == 1u) { v.x = v.x * 0.98f; v.y = v.y * 0.98f; v.z = v.z * 0.98f; }
-    if (m.color_spheres_mode == 1u) {
+    if (m.color_spheres_mode == 1u && !hide) {
         float e = eased_boost(m.color_spheres_boost_time, m.color_spheres_boost_duration);
         float damping = 0.98f * (1.0f - e) + 0.7f * e;
         v.x = v.x * damping; v.y = v.y * damping; v.z = v.z * damping;
     }
     for (int k = 0; k < FLOWMPM_SEGMENTS; k++) {
-        if (m.segment_mode[k] != 1u) continue;
+        if (m.segment_mode[k] != 1u || hide) continue;
         float e = eased_boost(m.segment_boost_time[k], m.segment_boost_duration[k]);
         float damping = 0.98f * (1.0f - e) + 0.7f * e;
         v.x = v.x * damping; v.y = v.y * damping; v.z = v.z * damping;
@@ -217,13 +228,33 @@ __device__ __forceinline__ Vec3 mode_damping(Vec3 v, const ModeParams *__restric
     return v;
 }
 
-// Everything after the gather when a mode is on: the mouse force only outside grid mode
-// (SIM:1355), then the dampings, then the common integration.
-__device__ __forceinline__ G2POut g2p_finish_modes(const G2PIn &in, Vec3 v, const float B[9], const Params &P,
-                                                   const ModeParams *__restrict__ M)
+// Everything after the gather when a mode is on: the mouse force only outside grid mode and
+// for visible particles (SIM:1355), the dampings, the parking of hidden particles, then the
+// common integration.
+//
+// Parking (SIM:1479-1513): `gridSize.x.mul(0.1)` has an int left operand, and three.js types a
+// binary operator by its left operand unless the right one is a longer vector, building both
+// operands in that type.  The literal becomes i32(0.1) = 0, the "edge region" is 0 wide and the
+// targets are the planes x = 0 and x = gridSize.x; the `.div(2.0)` on these ints divides by 2.
+__device__ __forceinline__ G2POut g2p_finish_modes(const G2PIn &in, Vec3 v, const float B[9], int index, bool hide,
+                                                   const Params &P, const ModeParams *__restrict__ M)
 {
-    if (M->grid_mode == 0u) v = g2p_mouse(in, v, P);
-    v = mode_damping(v, M);
+    if (M->grid_mode == 0u && !hide) v = g2p_mouse(in, v, P);
+    v = mode_damping(v, hide, M);
+    if (hide) {
+        const int edge_region_width = P.gx * (int)0.1f;
+        const int left_edge_max = edge_region_width, right_edge_min = P.gx - edge_region_width;
+        const float hash = (float)(unsigned)index * 12.9898f;
+        const bool use_left_edge = fract(hash) < 0.5f;
+        const int target_x = use_left_edge ? left_edge_max / 2 : right_edge_min + edge_region_width / 2;
+        const float dist = fabsf(in.px - (float)target_x);
+        if (dist > (float)(edge_region_width / 2)) {
+            const float toward = in.px < (float)target_x ? 1.0f : -1.0f;
+            const float excess = dist - (float)(edge_region_width / 2);
+            const float strength = excess * 0.3f;
+            v.x = v.x + (toward * strength) * P.dt;
+        }
+    }
     return g2p_integrate(in, v, B, P);
 }
 

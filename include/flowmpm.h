@@ -117,7 +117,8 @@ typedef struct {
     float mouse_ray_origin[3];        /* SIM:257, 1544 */
     float mouse_force[3];             /* SIM:258, 2533 */
     uint32_t cursor_interaction;      /* SIM:259 */
-    float hide_percentage;            /* SIM:260; must be 0 (FLOWMPM_ERR_UNSUPPORTED otherwise) */
+    float hide_percentage;            /* SIM:260, read at SIM:441-442; slab handles take 0 only
+                                       * (FLOWMPM_ERR_UNSUPPORTED otherwise) */
     uint32_t grid_mode;               /* SIM:152, read at SIM:444 */
     uint32_t front_gravity_mode;      /* SIM:153, read at SIM:485, 1316, 1365 */
 } flowmpm_uniforms;

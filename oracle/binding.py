@@ -128,7 +128,8 @@ def _ip(a):
 def make_uniforms(grid, num_particles, dt=0.1, stiffness=3.0, rest_density=2.5,
                   dynamic_viscosity=0.1, noise=1.0, time=0.0,
                   mouse_ray_direction=(0.0, 0.0, 0.0), mouse_ray_origin=(0.0, 0.0, 0.0),
-                  mouse_force=(0.0, 0.0, 0.0), cursor_interaction=0, grid_mode=0, front_gravity_mode=0):
+                  mouse_force=(0.0, 0.0, 0.0), cursor_interaction=0, grid_mode=0, front_gravity_mode=0,
+                  hide_percentage=0.0):
     u = Uniforms()
     u.grid_x, u.grid_y, u.grid_z = (int(g) for g in grid)
     u.num_particles = int(num_particles)
@@ -138,7 +139,7 @@ def make_uniforms(grid, num_particles, dt=0.1, stiffness=3.0, rest_density=2.5,
     u.mouse_ray_origin[:] = mouse_ray_origin
     u.mouse_force[:] = mouse_force
     u.cursor_interaction = int(cursor_interaction)
-    u.hide_percentage = 0.0
+    u.hide_percentage = float(hide_percentage)
     u.grid_mode = int(grid_mode)
     u.front_gravity_mode = int(front_gravity_mode)
     return u

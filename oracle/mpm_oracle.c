@@ -404,8 +404,11 @@ static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc
     const float gs[3] = { (float)u->grid_x, (float)u->grid_y, (float)u->grid_z };
     const int gsi[3] = { u->grid_x, u->grid_y, u->grid_z };
     const float dt = u->dt;
+    /* SIM:441-442 the first hidePercentage percent of the buffer are "hidden" */
+    const float index_percent = ((float)(uint32_t)index / (float)u->num_particles) * 100.0f;
+    const int hide = u->hide_percentage > 0.0f && index_percent < u->hide_percentage;
 
-    if (u->grid_mode == 1u) {
+    if (u->grid_mode == 1u && !hide) {
         /* SIM:445-482 attraction to a target on the image grid */
         int32_t gw = (int32_t)m->grid_width;
         int32_t gxi = gw ? index % gw : 0;         /* WGSL: x % 0 = 0, x / 0 = x */
@@ -427,7 +430,7 @@ static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc
         float dist = length3(to);
         float dir[3] = { to[0] / dist, to[1] / dist, to[2] / dist };
         push(v, dir, dist * 10.0f, dt);
-    } else if (u->front_gravity_mode == 1u) {
+    } else if (u->front_gravity_mode == 1u && !hide) {
         /* SIM:485-488: pull toward -z */
         const float front[3] = { 0.0f, 0.0f, -1.0f };
         for (int a = 0; a < 3; a++) v[a] = v[a] + (front[a] * 0.1f) * dt;
@@ -440,7 +443,7 @@ static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc
     }
 
     /* SIM:497-511 cylinder repulsion */
-    if (m->cylinder_mode == 1u) {
+    if (m->cylinder_mode == 1u && !hide) {
         float to[3] = { pos[0] - m->cylinder_center_x, pos[1] - m->cylinder_center_y, pos[2] - pos[2] };
         float flat[3] = { to[0], to[1], 0.0f };
         float dist = length3(flat);
@@ -451,11 +454,11 @@ static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc
         }
     }
     /* SIM:514-529 sphere containment, SIM:532-547 two-colour sphere */
-    if (m->sphere_containment_mode == 1u) contain_in_sphere(v, pos, m->sphere_center, m->sphere_radius, 0, 0.0f, dt);
-    if (m->two_color_sphere_mode == 1u) contain_in_sphere(v, pos, m->sphere_center, m->sphere_radius, 0, 0.0f, dt);
+    if (m->sphere_containment_mode == 1u && !hide) contain_in_sphere(v, pos, m->sphere_center, m->sphere_radius, 0, 0.0f, dt);
+    if (m->two_color_sphere_mode == 1u && !hide) contain_in_sphere(v, pos, m->sphere_center, m->sphere_radius, 0, 0.0f, dt);
 
     /* SIM:550-696 polygon containment in the xy plane */
-    if (m->polygon_containment_mode == 1u) {
+    if (m->polygon_containment_mode == 1u && !hide) {
         const float px = pos[0], py = pos[1];
         int inside = 0;
         const int count = (int)m->polygon_vertex_count;
@@ -496,7 +499,7 @@ static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc
     }
 
     /* SIM:699-759 colour spheres */
-    if (m->color_spheres_mode == 1u) {
+    if (m->color_spheres_mode == 1u && !hide) {
         float min_dist = 999.0f;
         int closest = 0;
         for (int i = 0; i < 10; i++) {
@@ -512,7 +515,7 @@ static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc
     /* SIM:762-1313 population segments: main sphere for everyone, a smaller sphere for the
      * segment's colour, and a negative-space sphere that repels */
     for (int k = 0; k < ORC_SEGMENTS; k++) {
-        if (m->segment_mode[k] != 1u) continue;
+        if (m->segment_mode[k] != 1u || hide) continue;
         float cd[3] = { color[0] - k_segment_color[k][0], color[1] - k_segment_color[k][1],
                         color[2] - k_segment_color[k][2] };
         int is_segment = length3(cd) < 0.1f;
@@ -533,9 +536,9 @@ static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc
         for (int a = 0; a < 3; a++) v[a] = v[a] - (n[a] * u->noise) * dt;
     }
 
-    /* SIM:1322-1352 gather, skipped in grid mode */
+    /* SIM:1322-1352 gather, skipped in grid mode and for hidden particles */
     float B[3][3] = { { 0 } };
-    if (u->grid_mode == 0u) {
+    if (u->grid_mode == 0u && !hide) {
         int ci[3];
         float w[3][3];
         bspline(pos, ci, w);
@@ -555,7 +558,7 @@ static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc
     }
 
     /* SIM:1355-1360 mouse force */
-    if (u->grid_mode == 0u && u->cursor_interaction == 1u) {
+    if (u->grid_mode == 0u && u->cursor_interaction == 1u && !hide) {
         const float *rd = u->mouse_ray_direction, *ro = u->mouse_ray_origin;
         float b[3] = { pos[0] * 1.0f - ro[0], pos[1] * 1.0f - ro[1], pos[2] * 0.4f - ro[2] };
         float cr[3] = { rd[1] * b[2] - rd[2] * b[1], rd[2] * b[0] - rd[0] * b[2], rd[0] * b[1] - rd[1] * b[0] };
@@ -571,16 +574,37 @@ static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc
     /* SIM:1365-1476 damping */
     if (u->front_gravity_mode == 1u)
         for (int a = 0; a < 3; a++) v[a] = v[a] * 0.98f;
-    if (m->color_spheres_mode == 1u) {
+    if (m->color_spheres_mode == 1u && !hide) {
         float e = eased_boost(m->color_spheres_boost_time, m->color_spheres_boost_duration);
         float damping = 0.98f * (1.0f - e) + 0.7f * e;
         for (int a = 0; a < 3; a++) v[a] = v[a] * damping;
     }
     for (int k = 0; k < ORC_SEGMENTS; k++) {
-        if (m->segment_mode[k] != 1u) continue;
+        if (m->segment_mode[k] != 1u || hide) continue;
         float e = eased_boost(m->segment_boost_time[k], m->segment_boost_duration[k]);
         float damping = 0.98f * (1.0f - e) + 0.7f * e;
         for (int a = 0; a < 3; a++) v[a] = v[a] * damping;
+    }
+
+    /* SIM:1479-1513 hidden particles are parked at the x faces.  `gridSize.x.mul(0.1)` has an
+     * int left operand, and three.js types a binary operator by its left operand unless the
+     * right one is a longer vector, building both operands in that type: the literal becomes
+     * i32(0.1) = 0, the "edge region" has width 0, and the targets are the planes x = 0 and
+     * x = gridSize.x.  The later `.div(2.0)` on these ints is an integer division by 2. */
+    if (hide) {
+        const int edge_region_width = u->grid_x * (int)0.1f;
+        const int left_edge_max = edge_region_width;
+        const int right_edge_min = u->grid_x - edge_region_width;
+        const float hash = (float)(uint32_t)index * 12.9898f;
+        const int use_left_edge = fractf(hash) < 0.5f;
+        const int target_x = use_left_edge ? left_edge_max / 2 : right_edge_min + edge_region_width / 2;
+        const float dist = fabsf(pos[0] - (float)target_x);
+        if (dist > (float)(edge_region_width / 2)) {
+            const float toward = pos[0] < (float)target_x ? 1.0f : -1.0f;
+            const float excess = dist - (float)(edge_region_width / 2);
+            const float strength = excess * 0.3f;
+            v[0] = v[0] + (toward * strength) * dt;
+        }
     }
 
     /* SIM:1515-1533 */

@@ -17,9 +17,12 @@
  * reference's arithmetic (see tests/test_oracle.py).
  *
  * The mode branches of g2p (orc_g2p_modes) are restated by this C file only (no numpy twin).
- * The hide-percentage edge parking (SIM:1479-1513) is NOT restated: `gridSize.x.mul(0.1)`
- * multiplies an int uniform by a float literal, and whether three.js 0.176 emits that as
- * i32(0.1) = 0 or as a float product cannot be settled without three.js itself.
+ * Two of its expressions depend on how three.js types a binary operator whose operands differ
+ * (`gridSize.sub(1)` at SIM:490 and `gridSize.x.mul(0.1)` at SIM:1481): this restatement
+ * follows three.js's OperatorNode, which takes the left operand's type unless the right one
+ * is a longer vector and converts both operands to it.  For SIM:490 both readings agree; for
+ * the hide-percentage edge parking (SIM:1479-1513) the int reading makes the edge regions
+ * zero wide.  Without three.js itself that reading cannot be confirmed.
  *
  * Arithmetic conventions (WGSL semantics, which is what three.js emits):
  *   - i32(f32): truncate toward zero, saturating, NaN -> 0
@@ -57,7 +60,7 @@ typedef struct {
     float mouse_ray_origin[3];           /* :257 */
     float mouse_force[3];                /* :258 */
     uint32_t cursor_interaction;         /* :259 */
-    float hide_percentage;               /* :260 (only 0 is restated) */
+    float hide_percentage;               /* :260 (orc_g2p ignores it; orc_g2p_modes honours it) */
     uint32_t grid_mode;                  /* :152 (orc_g2p ignores it; orc_g2p_modes honours it) */
     uint32_t front_gravity_mode;         /* :153 (as grid_mode) */
 } orc_uniforms;
@@ -96,9 +99,9 @@ void orc_p2g1(const float *particles, int32_t *cell, const orc_uniforms *u);
 void orc_p2g2(float *particles, int32_t *cell, const orc_uniforms *u);
 void orc_update_grid(const int32_t *cell, float *cellf, const orc_uniforms *u);
 void orc_g2p(float *particles, const float *cellf, const orc_uniforms *u);
-/* g2p with every mode branch of SIM:431-1536 except the hide-percentage edge parking
- * (SIM:441-442, 1479-1513; u->hide_percentage must be 0).  u->grid_mode and
- * u->front_gravity_mode are honoured.  m == NULL means all mode uniforms are zero. */
+/* g2p with every mode branch of SIM:431-1536, the hide-percentage edge parking included;
+ * u->grid_mode, u->front_gravity_mode and u->hide_percentage are honoured (u->num_particles
+ * is uniforms.numParticles).  m == NULL means all mode uniforms are zero. */
 void orc_g2p_modes(float *particles, const float *cellf, const orc_uniforms *u,
                    const orc_mode_uniforms *m);
 /* The same over a subset of the reference's buffer: ids[i] is the instanceIndex of record i

@@ -84,6 +84,18 @@ def case(name):
         uni["grid_mode"] = 1
         m.update(grid_width=0, grid_height=0, grid_start_x=4.0, grid_start_y=2.0,
                  grid_spacing_x=0.75, grid_spacing_y=0.75)
+    elif name == "hide_30":
+        uni["hide_percentage"] = 30.0
+    elif name == "hide_60_sphere_mouse":
+        uni["hide_percentage"] = 60.0
+        uni["cursor_interaction"] = 1
+        uni["mouse_ray_direction"], uni["mouse_ray_origin"] = (0.0, 0.0, 1.0), (64.0, 32.0, 0.0)
+        uni["mouse_force"] = (0.5, -0.25, 0.125)
+        m["sphere_containment_mode"] = 1
+    elif name == "hide_100_front_gravity_segment":
+        uni["hide_percentage"] = 100.0
+        uni["front_gravity_mode"] = 1
+        m["segment_mode"], m["segment_boost_time"] = [0, 1, 0, 0, 0, 0, 0, 0, 0], [0.0, 0.7] + [0.0] * 7
     elif name == "everything":
         uni["cursor_interaction"] = 1
         uni["mouse_ray_direction"], uni["mouse_ray_origin"] = (0.0, 0.0, 1.0), (64.0, 32.0, 0.0)
@@ -100,7 +112,8 @@ def case(name):
 
 ALL_CASES = (["none", "front_gravity", "front_gravity_cylinder", "sphere", "two_color_sphere", "polygon",
               "polygon_16", "polygon_empty", "color_spheres"] + ["segment_%d" % k for k in range(9)] +
-             ["image_grid", "image_grid_zero_width", "everything"])
+             ["image_grid", "image_grid_zero_width", "everything", "hide_30", "hide_60_sphere_mouse",
+              "hide_100_front_gravity_segment"])
 
 
 def fill(struct_type, fields):

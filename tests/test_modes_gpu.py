@@ -140,10 +140,12 @@ def test_mode_errors(oracle_binding):
     with pytest.raises(_lib.FlowMpmError) as e:
         h.set_mode_uniforms(bad)
     assert e.value.code == _lib.ERR_INVALID
-    with pytest.raises(_lib.FlowMpmError) as e:
-        h.set_uniforms(hide_percentage=10.0)
-    assert e.value.code == _lib.ERR_UNSUPPORTED
     h.close()
+    slab = flow_amd.Handle((16, 16, 16), 16, slab=(4, 8))
+    with pytest.raises(_lib.FlowMpmError) as e:
+        slab.set_uniforms(hide_percentage=10.0)
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    slab.close()
 
 
 def test_simulator_class_toggle_grid_mode(oracle_binding):

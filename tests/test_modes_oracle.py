@@ -296,3 +296,33 @@ def test_image_grid_setup_and_colours(tmp_path):
     assert mh.currentImageMode == 1                          # SIM:2280-2282: kept through mode 3
     mh.toggle(0, colors, 600)
     assert mh.currentImageMode is None
+
+
+def test_hidden_particles_are_parked_at_the_x_faces(oracle_binding):
+    """SIM:441-442, 1332, 1479-1513 under the int reading of `gridSize.x.mul(0.1)`: the first
+    hidePercentage percent of the buffer gather nothing and are pulled toward x = 0 or
+    x = gridSize.x, chosen by fract(index * 12.9898) < 0.5."""
+    ob = oracle_binding
+    n = 1000
+    rec = mode_cases.particles(n)
+    rec[:, 4:7] = 0
+    u = ob.make_uniforms(mode_cases.GRID, n, **dict(BASE, noise=0.0, hide_percentage=30.0))
+    m = mode_cases.fill(ob.ModeUniforms, mode_cases.case("none")[1])
+    orc = ob.Oracle(mode_cases.GRID)
+    orc.cellf[:, 0:3] = 0.25                       # a uniform flow on the grid for the others to gather
+    got = rec.copy()
+    orc.g2p_modes(got, u, m)
+    idx = np.arange(n)
+    hidden = (idx.astype(f32) / f32(n)) * f32(100.0) < f32(30.0)
+    assert hidden.sum() == 300
+    assert not got[hidden, 8:19].any() and got[~hidden, 8:19].any()
+    inner = ((rec[:, 0:3] > 6) & (rec[:, 0:3] < np.array(mode_cases.GRID) - 6)).all(axis=1)
+    h = idx.astype(f32) * f32(12.9898)
+    left = (h - np.floor(h)) < f32(0.5)
+    target = np.where(left, 0.0, 128.0)
+    sel = hidden & inner
+    # centre gravity (|v| = 0.01) plus the parking pull (|x - target| * 0.3 * dt) along x
+    pull = (target - rec[:, 0]) * 0.3 * 0.1
+    assert np.allclose(got[sel, 4], pull[sel], atol=0.011)
+    assert (np.sign(got[sel, 4]) == np.sign(pull[sel])).all()
+    assert np.allclose(got[~hidden & inner, 4], 0.25, atol=0.02)   # visible particles follow the grid

@@ -321,9 +321,6 @@ def test_errors_are_loud():
         h.upload_particles(np.zeros((11, 28), np.float32) + 8)
     assert e.value.code == _lib.ERR_CAPACITY
     with pytest.raises(_lib.FlowMpmError) as e:
-        h.set_uniforms(hide_percentage=25.0)
-    assert e.value.code == _lib.ERR_UNSUPPORTED
-    with pytest.raises(_lib.FlowMpmError) as e:
         h.run_kernel(99)
     assert e.value.code == _lib.ERR_INVALID
     h.close()
