@@ -372,6 +372,9 @@ class MlsMpmSimulator:
     def getDensities(self):
         return self.handle.download_field(_lib.FIELD_DENSITY)
 
+    def getDirections(self):
+        return self.handle.download_field(_lib.FIELD_DIRECTION)
+
     def getColors(self):
         """What material.colorNode reads: the device colours until toggleGridMode first
         rebinds the material to a rewritten buffer (SIM:2376-2384)."""

@@ -77,6 +77,26 @@ function closestPalette(color, rgb) {           // SIM:2196-2214
     return best;
 }
 
+// Binary PPM (P6, maxval 255) -> {width, height, channels: 3, data}.  Stands in for the browser's
+// Image + canvas decode (SIM:1550-1559); PNG / JPEG decoding is out of reach here.
+function readPpm(path) {
+    const data = require('fs').readFileSync(path);
+    const tokens = [];
+    let pos = 0;
+    const isSpace = (c) => c === 32 || (c >= 9 && c <= 13);
+    while (tokens.length < 4) {
+        while (isSpace(data[pos])) pos++;
+        if (data[pos] === 35) { pos = data.indexOf(10, pos) + 1; continue; }     // '#' comment
+        let end = pos;
+        while (!isSpace(data[end])) end++;
+        tokens.push(data.toString('latin1', pos, end));
+        pos = end;
+    }
+    if (tokens[0] !== 'P6' || Number(tokens[3]) !== 255) throw new Error(path + ': only binary PPM (P6) with maxval 255 is read');
+    const width = Number(tokens[1]), height = Number(tokens[2]);
+    return { width, height, channels: 3, data: new Uint8Array(data.buffer, data.byteOffset + pos + 1, width * height * 3) };
+}
+
 // Field order of flowmpm_mode_uniforms (include/flowmpm.h); every field is a 4-byte word.
 const LAYOUT = [['cylinder_mode', 'u', 1], ['sphere_containment_mode', 'u', 1], ['polygon_containment_mode', 'u', 1],
     ['color_spheres_mode', 'u', 1], ['two_color_sphere_mode', 'u', 1], ['segment_mode', 'u', 9],
@@ -219,8 +239,8 @@ class ModeHost {
         };
         if (enabled) {                                                              // SIM:2163-2277
             if (this.currentImageMode !== mode) {
-                if (!image) throw new Error('mode ' + mode + ' needs the decoded image {width, height, data}');
-                this.loadImageAndSetupGrid(image, n);
+                if (!image) throw new Error('mode ' + mode + ' needs the decoded image {width, height, data} or a PPM path');
+                this.loadImageAndSetupGrid(typeof image === 'string' ? readPpm(image) : image, n);
                 this.currentImageMode = mode;
             }
             const target = this.gridTargetColors;
@@ -305,5 +325,5 @@ class ModeHost {
     }
 }
 
-module.exports = { ModeHost, packFields, polygonVertices, colorSphereLayout, imageGrid, imageColors,
+module.exports = { ModeHost, readPpm, packFields, polygonVertices, colorSphereLayout, imageGrid, imageColors,
     closestPalette, COLOR_SPHERES_BOOST_DURATION, SEGMENT_NAMES, SEGMENT_ANGLES, MODE_UNIFORM_WORDS };

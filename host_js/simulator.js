@@ -131,6 +131,7 @@ class MlsMpmSimulator {
     getPositions() { return this._field('position', 3); }
     getVelocities() { return this._field('velocity', 3); }
     getDensities() { return this._field('density', 1); }
+    getDirections() { return this._field('direction', 3); }
     // What material.colorNode reads: the device colours until toggleGridMode first rebinds the
     // material to a rewritten buffer (SIM:2376-2384).
     getColors() {

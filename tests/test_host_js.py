@@ -122,6 +122,30 @@ def test_js_mode_host_agrees_with_python_mirror():
         np.testing.assert_allclose(got_colors, colors, rtol=1e-6, atol=1e-7, err_msg="colours, mode %d" % mode)
 
 
+def test_js_ppm_reader_and_image_mode(tmp_path):
+    from flow_amd import modes as host_modes
+    img = ((np.arange(30 * 20 * 3) * 37 + 11) % 256).astype(np.uint8).reshape(20, 30, 3)
+    ppm = tmp_path / "img.ppm"
+    ppm.write_bytes(b"P6\n# made by a test\n30 20\n255\n" + img.tobytes())
+    out = _node("""
+        const m = require('./host_js');
+        const p = m.modes.readPpm(process.argv[1]);
+        const u = {gridMode: {value: 0}, frontGravityMode: {value: 0}};
+        const mh = new m.modes.ModeHost(u, () => 1);
+        const arr = new Float32Array(700 * 28);
+        mh.toggle(7, arr, 28, 24, 600, process.argv[1]);
+        console.log(JSON.stringify({w: p.width, h: p.height, sum: p.data.reduce((a, b) => a + b, 0),
+            grid: [u.gridWidth.value, u.gridHeight.value, u.gridStartX.value, u.gridSpacingX.value],
+            first: [arr[24], arr[25], arr[26]], last: [arr[599 * 28 + 24], arr[599 * 28 + 25], arr[599 * 28 + 26]]}));
+    """, str(ppm))
+    d = json.loads(out)
+    assert (d["w"], d["h"], d["sum"]) == (30, 20, int(img.sum()))
+    gw, gh, sx, _, spacing = host_modes.image_grid(30, 20, 600)
+    assert d["grid"] == pytest.approx([gw, gh, sx, spacing])
+    want = host_modes.closest_palette(host_modes.image_colors(img, gw, gh, 600))
+    assert d["first"] == pytest.approx(list(want[0]), abs=1e-6) and d["last"] == pytest.approx(list(want[599]), abs=1e-6)
+
+
 def test_js_host_refuses_to_run_without_a_gpu():
     out = _node("""
         const m = require('./host_js');
