@@ -62,7 +62,9 @@ struct flowmpm_sim {
     int *mig_lists = nullptr;
     long long mig_list_cap = 0;
 
-    bool profiling = false;
+    bool profiling = false;      // the launches being enqueued right now are timed
+    int profile_stride = 0;      // 0 off, k: every k-th step of flowmpm_step
+    long long profile_step = 0;
     std::vector<EventPair> events;
     size_t events_used = 0;
     flowmpm_timings timings{};
@@ -122,10 +124,15 @@ void refresh_params(flowmpm_sim *s)
 
 // ---- timing -----------------------------------------------------------------
 
-int timing_begin(flowmpm_sim *s, int slot, size_t *idx, hipStream_t stream = nullptr)
+// A pair of events for one timed launch, or two null events when profiling is off.  The
+// events are attached to the kernel dispatch itself (hipExtLaunchKernelGGL), so they carry the
+// kernel's own start and end timestamps and put no extra packet into the queue: timing leaves
+// the schedule of the step as it is, and the durations are the ones a kernel trace reports.
+struct TimedLaunch { hipEvent_t start = nullptr, stop = nullptr; };
+
+int timing_events(flowmpm_sim *s, int slot, TimedLaunch *out)
 {
-    if (!stream) stream = s->stream;
-    *idx = (size_t)-1;
+    *out = TimedLaunch{};
     if (!s->profiling) return FLOWMPM_OK;
     if (s->events_used == s->events.size()) {
         EventPair p{};
@@ -133,16 +140,10 @@ int timing_begin(flowmpm_sim *s, int slot, size_t *idx, hipStream_t stream = nul
         HIP_TRY(s, hipEventCreate(&p.stop));
         s->events.push_back(p);
     }
-    *idx = s->events_used++;
-    s->events[*idx].slot = slot;
-    HIP_TRY(s, hipEventRecord(s->events[*idx].start, stream));
-    return FLOWMPM_OK;
-}
-
-int timing_end(flowmpm_sim *s, size_t idx, hipStream_t stream = nullptr)
-{
-    if (idx == (size_t)-1) return FLOWMPM_OK;
-    HIP_TRY(s, hipEventRecord(s->events[idx].stop, stream ? stream : s->stream));
+    EventPair &p = s->events[s->events_used++];
+    p.slot = slot;
+    out->start = p.start;
+    out->stop = p.stop;
     return FLOWMPM_OK;
 }
 
@@ -172,14 +173,13 @@ int launch_check(flowmpm_sim *s, const char *what)
 
 int stage_clear_grid(flowmpm_sim *s)
 {
-    size_t t;
-    int rc = timing_begin(s, FLOWMPM_KERNEL_CLEAR_GRID, &t);
+    TimedLaunch t;
+    int rc = timing_events(s, FLOWMPM_KERNEL_CLEAR_GRID, &t);
     if (rc) return rc;
     unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
-    hipLaunchKernelGGL(mpm::clear_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, s->cell,
-                       s->mass_i, s->cellf, s->local_cells);
-    if ((rc = launch_check(s, "clear_grid"))) return rc;
-    return timing_end(s, t);
+    hipExtLaunchKernelGGL(mpm::clear_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
+                          s->cell, s->mass_i, s->cellf, s->local_cells);
+    return launch_check(s, "clear_grid");
 }
 
 int stage_rebin_if_needed(flowmpm_sim *s);
@@ -189,38 +189,40 @@ int stage_p2g1(flowmpm_sim *s)
 {
     int rc;
     if (is_tiled(s) && (rc = stage_rebin_if_needed(s))) return rc;
-    size_t t;
-    if ((rc = timing_begin(s, FLOWMPM_KERNEL_P2G1, &t))) return rc;
     if (s->live > 0) {
+        TimedLaunch t;
+        if ((rc = timing_events(s, FLOWMPM_KERNEL_P2G1, &t))) return rc;
         if (is_tiled(s)) {
-            if ((rc = mpm::launch_p2g1_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream)))
+            if ((rc = mpm::launch_p2g1_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream, t.start,
+                                             t.stop)))
                 return fail(s, FLOWMPM_ERR_HIP, "p2g1_tiled launch failed");
         } else {
-            hipLaunchKernelGGL(mpm::p2g1_scatter_kernel, dim3(blocks_for(s->live, 256)), dim3(256), 0,
-                               s->stream, s->store, s->live, s->fixed(), s->params);
+            hipExtLaunchKernelGGL(mpm::p2g1_scatter_kernel, dim3(blocks_for(s->live, 256)), dim3(256), 0, s->stream,
+                                  t.start, t.stop, 0, s->store, s->live, s->fixed(), s->params);
         }
         if ((rc = launch_check(s, "p2g1"))) return rc;
     }
-    return timing_end(s, t);
+    return FLOWMPM_OK;
 }
 
 int stage_p2g2(flowmpm_sim *s)
 {
     int rc;
     if (is_tiled(s) && (rc = stage_rebin_if_needed(s))) return rc;
-    size_t t;
-    if ((rc = timing_begin(s, FLOWMPM_KERNEL_P2G2, &t))) return rc;
     if (s->live > 0) {
+        TimedLaunch t;
+        if ((rc = timing_events(s, FLOWMPM_KERNEL_P2G2, &t))) return rc;
         if (is_tiled(s)) {
-            if ((rc = mpm::launch_p2g2_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream)))
+            if ((rc = mpm::launch_p2g2_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream, t.start,
+                                             t.stop)))
                 return fail(s, FLOWMPM_ERR_HIP, "p2g2_tiled launch failed");
         } else {
-            hipLaunchKernelGGL(mpm::p2g2_scatter_kernel, dim3(blocks_for(s->live, 256)), dim3(256), 0,
-                               s->stream, s->store, s->live, s->fixed(), s->params);
+            hipExtLaunchKernelGGL(mpm::p2g2_scatter_kernel, dim3(blocks_for(s->live, 256)), dim3(256), 0, s->stream,
+                                  t.start, t.stop, 0, s->store, s->live, s->fixed(), s->params);
         }
         if ((rc = launch_check(s, "p2g2"))) return rc;
     }
-    return timing_end(s, t);
+    return FLOWMPM_OK;
 }
 
 inline bool is_tiled(const flowmpm_sim *s) { return s->cfg.algorithm != FLOWMPM_ALGO_SCATTER; }
@@ -231,27 +233,28 @@ int stage_p2g_pass(flowmpm_sim *s, bool momentum)
     int rc;
     if (!is_tiled(s)) return fail(s, FLOWMPM_ERR_INVALID, "the mass/momentum passes belong to the tiled algorithm");
     if ((rc = stage_rebin_if_needed(s))) return rc;
-    size_t t;
-    if ((rc = timing_begin(s, momentum ? FLOWMPM_KERNEL_P2G2 : FLOWMPM_KERNEL_P2G1, &t))) return rc;
     if (s->live > 0) {
-        rc = momentum ? mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream)
-                      : mpm::launch_p2g_mass_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream);
+        TimedLaunch t;
+        if ((rc = timing_events(s, momentum ? FLOWMPM_KERNEL_P2G2 : FLOWMPM_KERNEL_P2G1, &t))) return rc;
+        rc = momentum ? mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream,
+                                                       t.start, t.stop)
+                      : mpm::launch_p2g_mass_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream,
+                                                   t.start, t.stop);
         if (rc) return fail(s, FLOWMPM_ERR_HIP, "p2g pass: could not reset the straggler counter");
         if ((rc = launch_check(s, momentum ? "p2g_momentum" : "p2g_mass"))) return rc;
     }
-    return timing_end(s, t);
+    return FLOWMPM_OK;
 }
 
 int stage_update_grid(flowmpm_sim *s)
 {
-    size_t t;
-    int rc = timing_begin(s, FLOWMPM_KERNEL_UPDATE_GRID, &t);
+    TimedLaunch t;
+    int rc = timing_events(s, FLOWMPM_KERNEL_UPDATE_GRID, &t);
     if (rc) return rc;
     unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
-    hipLaunchKernelGGL(mpm::update_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, s->cell,
-                       s->mass_i, s->cellf, s->local_cells, s->params);
-    if ((rc = launch_check(s, "update_grid"))) return rc;
-    return timing_end(s, t);
+    hipExtLaunchKernelGGL(mpm::update_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
+                          s->cell, s->mass_i, s->cellf, s->local_cells, s->params);
+    return launch_check(s, "update_grid");
 }
 
 // True when any uniform that selects a mode branch of g2p is set.
@@ -295,23 +298,24 @@ int stage_g2p(flowmpm_sim *s)
         }
         modes = s->d_modes;
     }
-    size_t t;
-    if ((rc = timing_begin(s, FLOWMPM_KERNEL_G2P, &t))) return rc;
     if (s->live > 0) {
+        TimedLaunch t;
+        if ((rc = timing_events(s, FLOWMPM_KERNEL_G2P, &t))) return rc;
         if (is_tiled(s)) {
-            if ((rc = mpm::launch_g2p_tiled(s->tiled, s->store, s->live, s->cellf, s->params, modes, s->stream)))
+            if ((rc = mpm::launch_g2p_tiled(s->tiled, s->store, s->live, s->cellf, s->params, modes, s->stream,
+                                            t.start, t.stop)))
                 return fail(s, FLOWMPM_ERR_HIP, "g2p_tiled launch failed");
             s->tiled.checked = false;      // the next step decides anew
         } else if (modes) {
-            hipLaunchKernelGGL(mpm::g2p_gather_kernel<true>, dim3(blocks_for(s->live, 256)), dim3(256), 0,
-                               s->stream, s->store, s->live, s->cellf, s->params, modes);
+            hipExtLaunchKernelGGL(mpm::g2p_gather_kernel<true>, dim3(blocks_for(s->live, 256)), dim3(256), 0,
+                                  s->stream, t.start, t.stop, 0, s->store, s->live, s->cellf, s->params, modes);
         } else {
-            hipLaunchKernelGGL(mpm::g2p_gather_kernel<false>, dim3(blocks_for(s->live, 256)), dim3(256), 0,
-                               s->stream, s->store, s->live, s->cellf, s->params, modes);
+            hipExtLaunchKernelGGL(mpm::g2p_gather_kernel<false>, dim3(blocks_for(s->live, 256)), dim3(256), 0,
+                                  s->stream, t.start, t.stop, 0, s->store, s->live, s->cellf, s->params, modes);
         }
         if ((rc = launch_check(s, "g2p"))) return rc;
     }
-    return timing_end(s, t);
+    return FLOWMPM_OK;
 }
 
 // Tiled algorithm: particles must be grouped by grid tile before the first
@@ -321,13 +325,14 @@ int stage_rebin_if_needed(flowmpm_sim *s)
     mpm::TiledState &T = s->tiled;
     if (T.valid && T.checked) return FLOWMPM_OK;
     if (s->live == 0) return FLOWMPM_OK;
-    size_t t;
-    int rc = timing_begin(s, FLOWMPM_TIMING_REBIN, &t);
+    TimedLaunch t;      // from the start of the first binning kernel to the end of the second
+    int rc = timing_events(s, FLOWMPM_TIMING_REBIN, &t);
     if (rc) return rc;
     std::string msg;
-    if (mpm::rebin_if_due(T, s->store, s->live, s->params, s->cfg.rebin_interval, s->drift_divisor, s->stream, &msg))
+    if (mpm::rebin_if_due(T, s->store, s->live, s->params, s->cfg.rebin_interval, s->drift_divisor, s->stream,
+                          t.start, t.stop, &msg))
         return fail(s, FLOWMPM_ERR_HIP, "rebin: " + msg);
-    return timing_end(s, t);
+    return FLOWMPM_OK;
 }
 
 int validate_uniforms(flowmpm_sim *s, const flowmpm_uniforms *u)
@@ -586,6 +591,7 @@ int flowmpm_step(flowmpm_sim *s, int32_t n_steps, double dtime)
     int rc = FLOWMPM_OK;
     for (int k = 0; k < n_steps && rc == FLOWMPM_OK; k++) {
         s->params.time = (float)((double)time0 + (double)k * dtime);
+        s->profiling = s->profile_stride > 0 && (s->profile_step++ % s->profile_stride) == 0;
         if ((rc = stage_clear_grid(s))) break;
         if (s->cfg.algorithm == FLOWMPM_ALGO_TILED) {
             if ((rc = stage_p2g_pass(s, false))) break;
@@ -600,6 +606,7 @@ int flowmpm_step(flowmpm_sim *s, int32_t n_steps, double dtime)
         if (s->profiling && s->events_used > 4096 && (rc = timing_collect(s))) break;
     }
     s->params.time = time0;
+    s->profiling = s->profile_stride > 0;
     return rc;
 }
 
@@ -724,12 +731,15 @@ int flowmpm_download_grid_f32(flowmpm_sim *s, float *out, int64_t capacity_cells
     return FLOWMPM_OK;
 }
 
-int flowmpm_set_profiling(flowmpm_sim *s, int32_t enabled)
+int flowmpm_set_profiling(flowmpm_sim *s, int32_t every_nth_step)
 {
     CHECK_SIM(s);
+    if (every_nth_step < 0) return fail(s, FLOWMPM_ERR_INVALID, "negative sampling stride");
     int rc = timing_collect(s);
     if (rc) return rc;
-    s->profiling = enabled != 0;
+    s->profile_stride = every_nth_step;
+    s->profile_step = 0;
+    s->profiling = every_nth_step != 0;
     return FLOWMPM_OK;
 }
 

@@ -964,15 +964,15 @@ constexpr unsigned kBinBlocks = 2048;
 // first n particles of the current store are grouped by tile into the other store, the work
 // items are rebuilt and the other store becomes current.
 inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P, int interval, int divisor,
-                        hipStream_t stream, std::string *msg)
+                        hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, std::string *msg)
 {
     const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, kBinBlocks);
     const int force = T.valid ? 0 : 1;
-    hipLaunchKernelGGL(bin_count_scan_kernel, dim3(blocks), dim3(256), 0, stream, ss, (int)n, P, tile_dims(T), T.key,
-                       T.rank, T.tile_count, T.n_tiles, T.tile_start, T.items, T.n_items, T.item_cap, T.ctl,
-                       interval, force, divisor);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, stream, ss, (int)n, T.key, T.rank,
-                       T.tile_start, T.ctl, interval, force, divisor);
+    hipExtLaunchKernelGGL(bin_count_scan_kernel, dim3(blocks), dim3(256), 0, stream, ev_start, nullptr, 0, ss, (int)n,
+                          P, tile_dims(T), T.key, T.rank, T.tile_count, T.n_tiles, T.tile_start, T.items, T.n_items,
+                          T.item_cap, T.ctl, interval, force, divisor);
+    hipExtLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, stream, nullptr, ev_stop, 0, ss, (int)n,
+                          T.key, T.rank, T.tile_start, T.ctl, interval, force, divisor);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { *msg = std::string("rebin launch: ") + hipGetErrorString(e); return 1; }
     T.valid = true;
@@ -993,51 +993,56 @@ inline unsigned item_bound(const TiledState &T, long long n)
 }
 
 // Every tiled stage is: zero the straggler counter, the tiled kernel, the straggler kernel.
+// ev_start / ev_stop (may be null) receive the start and end timestamps of the tiled kernel.
 constexpr int kStragglerBlocks = 1024;
 
 #define FLOWMPM_TILED_STAGE(kernel, straggler_kernel, grid_ptr)                                              \
     do {                                                                                                    \
         if (hipMemsetAsync(T.stragglers.count, 0, sizeof(int), stream) != hipSuccess) return 1;             \
         const TiledWork w = tiled_work(T, st, n);                                                           \
-        hipLaunchKernelGGL(kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, w, grid_ptr, P); \
+        hipExtLaunchKernelGGL(kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, ev_start,     \
+                              ev_stop, 0, w, grid_ptr, P);                                                  \
         hipLaunchKernelGGL(straggler_kernel, dim3(kStragglerBlocks), dim3(256), 0, stream, w, grid_ptr, P); \
         return 0;                                                                                           \
     } while (0)
 
-inline int launch_p2g1_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
+inline int launch_p2g1_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream,
+                             hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     FLOWMPM_TILED_STAGE(p2g1_tiled_kernel, straggler_p2g_kernel<0>, g);
 }
 
-inline int launch_p2g2_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
+inline int launch_p2g2_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream,
+                             hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     FLOWMPM_TILED_STAGE(p2g2_tiled_kernel, straggler_p2g_kernel<1>, g);
 }
 
-inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream)
+inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream,
+                             hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     FLOWMPM_TILED_STAGE(p2g_mass_tiled_kernel, straggler_p2g_kernel<2>, g);
 }
 
 inline int launch_p2g_momentum_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P,
-                                     hipStream_t stream)
+                                     hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     FLOWMPM_TILED_STAGE(p2g_momentum_tiled_kernel, straggler_p2g_kernel<3>, g);
 }
 
 // modes == nullptr: chaos path.
 inline int launch_g2p_tiled(TiledState &T, StoreSel st, long long n, const float4 *cellf, const Params &P,
-                            const ModeParams *modes, hipStream_t stream)
+                            const ModeParams *modes, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (hipMemsetAsync(T.stragglers.count, 0, sizeof(int), stream) != hipSuccess) return 1;
     const dim3 grid(item_bound(T, n)), block(kTiledThreads);
     const TiledWork w = tiled_work(T, st, n);
     if (modes) {
-        hipLaunchKernelGGL(g2p_tiled_kernel<true>, grid, block, 0, stream, w, cellf, P, modes);
+        hipExtLaunchKernelGGL(g2p_tiled_kernel<true>, grid, block, 0, stream, ev_start, ev_stop, 0, w, cellf, P, modes);
         hipLaunchKernelGGL(straggler_g2p_kernel<true>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, cellf, P,
                            modes);
     } else {
-        hipLaunchKernelGGL(g2p_tiled_kernel<false>, grid, block, 0, stream, w, cellf, P, modes);
+        hipExtLaunchKernelGGL(g2p_tiled_kernel<false>, grid, block, 0, stream, ev_start, ev_stop, 0, w, cellf, P, modes);
         hipLaunchKernelGGL(straggler_g2p_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, cellf, P,
                            modes);
     }

@@ -12,6 +12,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace mpm {
@@ -51,10 +52,24 @@ __device__ __forceinline__ int f32_to_i32(float f)
     return r;
 }
 
+// x / c for a compile-time constant c in three instructions instead of the dozen of an IEEE
+// division: q0 = x * RN(1/c), one residual, one correction.  Bit-identical to x / c for
+// x = +0 and every binary32 x with 2^-25 <= |x| <= 2^31, for the five divisors used here
+// (checked over all 2^32 bit patterns by tools/ubench/const_div.hip; outside that range
+// results that are subnormal can differ, and -0 yields +0).  Callers only pass values from
+// that range: tri() returns 0 or [2^-25, 0.5], and decode_fixed converts an i32.
+__device__ __forceinline__ float div_by_const(float x, float c)
+{
+    const float rc = 1.0f / c;
+    const float q0 = x * rc;
+    const float r = __builtin_fmaf(-c, q0, x);
+    return __builtin_fmaf(r, rc, q0);
+}
+
 // SIM:279-281 encodeFixedPoint, fixedPointMultiplier = 1e7 (SIM:43).
 __device__ __forceinline__ int encode_fixed(float f) { return f32_to_i32(f * 1.0e7f); }
 // SIM:282-284 decodeFixedPoint.
-__device__ __forceinline__ float decode_fixed(int i) { return (float)i / 1.0e7f; }
+__device__ __forceinline__ float decode_fixed(int i) { return div_by_const((float)i, 1.0e7f); }
 
 __device__ __forceinline__ float fract(float x) { return x - floorf(x); }
 
@@ -111,7 +126,8 @@ __device__ __forceinline__ Vec3 tri_noise3d(Vec3 position, float speed, float ti
         float i0 = tri(py), i1 = tri(pz), i2 = tri(px);
         float m0 = tri(px + i0), m1 = tri(py + i1), m2 = tri(pz + i2);
         float t0 = tri(pz + m0), t1 = tri(px + m1), t2 = tri(py + m2);
-        rx = rx + t0 / z; ry = ry + t1 / z; rz = rz + t2 / z;
+        // z is a compile-time constant here (the loop is unrolled): 2.1, 3.15, 4.725, 7.0875
+        rx = rx + div_by_const(t0, z); ry = ry + div_by_const(t1, z); rz = rz + div_by_const(t2, z);
         bx = bx + 0.14f; by = by + 0.14f; bz = bz + 0.14f;
     }
     return Vec3{rx, ry, rz};

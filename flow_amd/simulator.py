@@ -147,8 +147,9 @@ class Handle:
         self._chk(self.L.flowmpm_download_grid_f32(self._h, _fp(out), cells))
         return out
 
-    def set_profiling(self, enabled):
-        self._chk(self.L.flowmpm_set_profiling(self._h, 1 if enabled else 0))
+    def set_profiling(self, every_nth_step):
+        """0 / False: off; 1 / True: every launch; k: the launches of every k-th step()."""
+        self._chk(self.L.flowmpm_set_profiling(self._h, int(every_nth_step)))
 
     def reset_timings(self):
         self._chk(self.L.flowmpm_reset_timings(self._h))

@@ -218,8 +218,13 @@ int flowmpm_get_local_grid(flowmpm_sim *sim, int32_t *x_first, int32_t *x_planes
 int flowmpm_download_grid_i32(flowmpm_sim *sim, int32_t *out, int64_t capacity_cells);
 int flowmpm_download_grid_f32(flowmpm_sim *sim, float *out, int64_t capacity_cells);
 
-/* Per-kernel device timing with HIP events on the handle's stream. */
-int flowmpm_set_profiling(flowmpm_sim *sim, int32_t enabled);
+/* Per-kernel device timing: HIP events attached to the kernel dispatches on the handle's
+ * stream (start and end timestamps of the kernel itself).  every_nth_step = 0 switches it
+ * off, 1 times every launch, k > 1 times the launches of every k-th step of flowmpm_step
+ * (a timed dispatch costs the queue a few microseconds; sampling keeps a timed run within a
+ * fraction of a percent of an untimed one).  flowmpm_run_kernel launches are timed whenever
+ * the value is not 0. */
+int flowmpm_set_profiling(flowmpm_sim *sim, int32_t every_nth_step);
 int flowmpm_get_timings(flowmpm_sim *sim, flowmpm_timings *out);
 int flowmpm_reset_timings(flowmpm_sim *sim);
 
