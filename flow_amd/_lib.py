@@ -22,6 +22,7 @@ FIELD_WIDTH = {FIELD_POSITION: 3, FIELD_VELOCITY: 3, FIELD_DENSITY: 1, FIELD_COL
                FIELD_DIRECTION: 3, FIELD_MASS: 1}
 PLANE_LOW_HALO, PLANE_LOW_OWNED, PLANE_HIGH_OWNED, PLANE_HIGH_HALO = range(4)
 COMP_MOMENTUM, COMP_MASS, COMP_ALL = 0x7, 0x8, 0xF
+SIDE_LOW, SIDE_HIGH = 0, 1
 MIGRATE_WORDS = 24
 SEGMENTS = 9
 # Order of the population-segment entries in ModeUniforms (SIM:761-1313).
@@ -36,7 +37,8 @@ EXPORTS = (
     "flowmpm_get_local_grid", "flowmpm_download_grid_i32", "flowmpm_download_grid_f32",
     "flowmpm_set_profiling", "flowmpm_get_timings", "flowmpm_reset_timings", "flowmpm_plane_bytes",
     "flowmpm_plane_add_i32", "flowmpm_plane_copy_out", "flowmpm_extract_leavers",
-    "flowmpm_insert_arrivals", "flowmpm_set_mode_uniforms",
+    "flowmpm_insert_arrivals", "flowmpm_set_mode_uniforms", "flowmpm_halo_words", "flowmpm_halo_pack",
+    "flowmpm_halo_add",
 )
 
 
@@ -153,6 +155,9 @@ def load():
         "flowmpm_extract_leavers": ([vp, ip, i32, vp, i64, i64p], ctypes.c_int),
         "flowmpm_insert_arrivals": ([vp, vp, i64], ctypes.c_int),
         "flowmpm_set_mode_uniforms": ([vp, ctypes.POINTER(ModeUniforms)], ctypes.c_int),
+        "flowmpm_halo_words": ([vp, u32, i64p], ctypes.c_int),
+        "flowmpm_halo_pack": ([vp, i32, u32, vp], ctypes.c_int),
+        "flowmpm_halo_add": ([vp, i32, u32, vp], ctypes.c_int),
     }
     for name, (argtypes, restype) in protos.items():
         fn = getattr(L, name)

@@ -822,6 +822,56 @@ int flowmpm_plane_copy_out(flowmpm_sim *s, int32_t plane, void *dev_dst)
     return launch_check(s, "plane_copy_out");
 }
 
+// First cell and cell count of the two adjacent boundary planes of one side.
+static int halo_pair(flowmpm_sim *s, int32_t side, uint32_t comp_mask, long long *first, long long *cells, int *k)
+{
+    if (!s->slab) return fail(s, FLOWMPM_ERR_INVALID, "not a slab handle");
+    if (side != FLOWMPM_SIDE_LOW && side != FLOWMPM_SIDE_HIGH) return fail(s, FLOWMPM_ERR_INVALID, "unknown side");
+    if ((comp_mask & 0xFu) == 0 || (comp_mask & ~0xFu)) return fail(s, FLOWMPM_ERR_INVALID, "bad component mask");
+    const long long plane = (long long)s->cfg.grid_y * s->cfg.grid_z;
+    *first = (side == FLOWMPM_SIDE_LOW ? 0 : (long long)s->cfg.slab_nx) * plane;
+    *cells = 2 * plane;
+    *k = __builtin_popcount(comp_mask & 0xFu);
+    return FLOWMPM_OK;
+}
+
+int flowmpm_halo_words(flowmpm_sim *s, uint32_t comp_mask, int64_t *words)
+{
+    if (!s) return fail(nullptr, FLOWMPM_ERR_INVALID, "null handle");
+    long long first, cells;
+    int k;
+    int rc = halo_pair(s, FLOWMPM_SIDE_LOW, comp_mask, &first, &cells, &k);
+    if (rc) return rc;
+    if (words) *words = cells * k;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_halo_pack(flowmpm_sim *s, int32_t side, uint32_t comp_mask, void *dev_dst)
+{
+    CHECK_SIM(s);
+    long long first, cells;
+    int k;
+    int rc = halo_pair(s, side, comp_mask, &first, &cells, &k);
+    if (rc) return rc;
+    if (!dev_dst) return fail(s, FLOWMPM_ERR_INVALID, "null destination");
+    hipLaunchKernelGGL(mpm::halo_pack_kernel, dim3(blocks_for(cells, 256)), dim3(256), 0, s->stream, s->cell + first,
+                       s->mass_i + first, reinterpret_cast<int *>(dev_dst), cells, comp_mask & 0xFu, k);
+    return launch_check(s, "halo_pack");
+}
+
+int flowmpm_halo_add(flowmpm_sim *s, int32_t side, uint32_t comp_mask, const void *dev_src)
+{
+    CHECK_SIM(s);
+    long long first, cells;
+    int k;
+    int rc = halo_pair(s, side, comp_mask, &first, &cells, &k);
+    if (rc) return rc;
+    if (!dev_src) return fail(s, FLOWMPM_ERR_INVALID, "null source");
+    hipLaunchKernelGGL(mpm::halo_add_kernel, dim3(blocks_for(cells, 256)), dim3(256), 0, s->stream, s->cell + first,
+                       s->mass_i + first, reinterpret_cast<const int *>(dev_src), cells, comp_mask & 0xFu, k);
+    return launch_check(s, "halo_add");
+}
+
 int flowmpm_extract_leavers(flowmpm_sim *s, const int32_t *plane_starts, int32_t n_ranks, void *dev_out,
                             int64_t capacity_records, int64_t *counts)
 {

@@ -316,6 +316,42 @@ plane_add_kernel(int4 *__restrict__ dst, int *__restrict__ dst_mass, const int4 
     if (mask & 8u) dst_mass[i] = (int)((unsigned)dst_mass[i] + (unsigned)s.w);
 }
 
+// Halo exchange with only the components a merge needs: `cells` consecutive cells (the two
+// boundary planes of one side are adjacent in memory) packed as k = popcount(mask) words per
+// cell, components in x, y, z, mass order.
+__global__ void __launch_bounds__(256)
+halo_pack_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass, int *__restrict__ out,
+                 long long cells, unsigned mask, int k)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    int *o = out + i * k;
+    if (mask & 7u) {
+        int4 c = cell[i];
+        if (mask & 1u) *o++ = c.x;
+        if (mask & 2u) *o++ = c.y;
+        if (mask & 4u) *o++ = c.z;
+    }
+    if (mask & 8u) *o = mass[i];
+}
+
+__global__ void __launch_bounds__(256)
+halo_add_kernel(int4 *__restrict__ dst, int *__restrict__ dst_mass, const int *__restrict__ src,
+                long long cells, unsigned mask, int k)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    const int *p = src + i * k;
+    if (mask & 7u) {
+        int4 d = dst[i];
+        if (mask & 1u) d.x = (int)((unsigned)d.x + (unsigned)*p++);
+        if (mask & 2u) d.y = (int)((unsigned)d.y + (unsigned)*p++);
+        if (mask & 4u) d.z = (int)((unsigned)d.z + (unsigned)*p++);
+        dst[i] = d;
+    }
+    if (mask & 8u) dst_mass[i] = (int)((unsigned)dst_mass[i] + (unsigned)*p);
+}
+
 // The reference's cell records {x, y, z, mass} of `cells` consecutive cells, assembled from
 // the device layout (downloads, halo-plane send staging).
 __global__ void __launch_bounds__(256)

@@ -174,6 +174,17 @@ class Handle:
     def plane_copy_out(self, plane, dev_dst):
         self._chk(self.L.flowmpm_plane_copy_out(self._h, int(plane), ctypes.c_void_p(dev_dst)))
 
+    def halo_words(self, comp_mask):
+        words = ctypes.c_int64()
+        self._chk(self.L.flowmpm_halo_words(self._h, int(comp_mask), ctypes.byref(words)))
+        return words.value
+
+    def halo_pack(self, side, comp_mask, dev_dst):
+        self._chk(self.L.flowmpm_halo_pack(self._h, int(side), int(comp_mask), ctypes.c_void_p(dev_dst)))
+
+    def halo_add(self, side, comp_mask, dev_src):
+        self._chk(self.L.flowmpm_halo_add(self._h, int(side), int(comp_mask), ctypes.c_void_p(dev_src)))
+
     def extract_leavers(self, plane_starts, dev_out, capacity_records):
         starts = np.ascontiguousarray(plane_starts, dtype=np.int32)
         n_ranks = starts.shape[0] - 1

@@ -11,8 +11,9 @@ one xGMI link per neighbour; no all-reduce on the data path):
   clearGrid, p2g1
   exchange A  both boundary planes (halo + first owned) go to the neighbour, which adds the
               MASS component into its matching planes            -> mass complete for p2g2
+              (4 bytes per cell travel)
   p2g2
-  exchange B  same planes again, the neighbour adds the MOMENTUM components
+  exchange B  same planes again, the neighbour adds the MOMENTUM components (12 bytes per cell)
   updateGrid  on owned and halo planes alike (redundant on halos, saves a third exchange)
   g2p
   migrate     particles whose floor(x) left the slab are packed, counted (one small
@@ -138,6 +139,15 @@ class GpuSlabBackend:
     def plane_add(self, plane, src, mask):
         self.handle.plane_add_i32(plane, src.data_ptr(), mask)
 
+    def new_halo_buffer(self, mask):
+        return torch.empty(self.handle.halo_words(mask), dtype=torch.int32, device=self.torch_device)
+
+    def halo_pack(self, side, mask, out):
+        self.handle.halo_pack(side, mask, out.data_ptr())
+
+    def halo_add(self, side, mask, src):
+        self.handle.halo_add(side, mask, src.data_ptr())
+
     def extract_leavers(self, plane_starts):
         counts = self.handle.extract_leavers(plane_starts, self._leavers.data_ptr(), self._leavers.shape[0])
         return counts, self._leavers[: int(counts.sum())]
@@ -176,8 +186,9 @@ class SlabSimulation:
         self.low = rank - 1 if rank > 0 else None
         self.high = rank + 1 if rank < world - 1 else None
         b = self.backend
-        self._send = {side: b.new_plane_buffer(2) for side in ("low", "high")}
-        self._recv = {side: b.new_plane_buffer(2) for side in ("low", "high")}
+        masks = (_lib.COMP_MASS, _lib.COMP_MOMENTUM)
+        self._send = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
+        self._recv = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
 
     # ---- set-up ----
     def set_uniforms(self, **kw):
@@ -239,29 +250,25 @@ class SlabSimulation:
 
     # ---- the step ----
     def _exchange_planes(self, mask):
+        """Both boundary planes of each side go to that side's neighbour, which adds them into
+        its matching pair: my LOW pair (planes x0-1, x0) is the low neighbour's HIGH pair."""
         if self.transport is None:
             return
         b = self.backend
         sends, recvs = [], []
         if self.low is not None:
-            b.plane_read(_lib.PLANE_LOW_HALO, self._send["low"][0])
-            b.plane_read(_lib.PLANE_LOW_OWNED, self._send["low"][1])
-            sends.append((self._send["low"], self.low))
-            recvs.append((self._recv["low"], self.low))
+            b.halo_pack(_lib.SIDE_LOW, mask, self._send["low", mask])
+            sends.append((self._send["low", mask], self.low))
+            recvs.append((self._recv["low", mask], self.low))
         if self.high is not None:
-            b.plane_read(_lib.PLANE_HIGH_OWNED, self._send["high"][0])
-            b.plane_read(_lib.PLANE_HIGH_HALO, self._send["high"][1])
-            sends.append((self._send["high"], self.high))
-            recvs.append((self._recv["high"], self.high))
+            b.halo_pack(_lib.SIDE_HIGH, mask, self._send["high", mask])
+            sends.append((self._send["high", mask], self.high))
+            recvs.append((self._recv["high", mask], self.high))
         self.transport.exchange(sends, recvs)
-        # The low neighbour sent (its HIGH_OWNED, its HIGH_HALO) = (my LOW_HALO, my LOW_OWNED).
         if self.low is not None:
-            b.plane_add(_lib.PLANE_LOW_HALO, self._recv["low"][0], mask)
-            b.plane_add(_lib.PLANE_LOW_OWNED, self._recv["low"][1], mask)
-        # The high neighbour sent (its LOW_HALO, its LOW_OWNED) = (my HIGH_OWNED, my HIGH_HALO).
+            b.halo_add(_lib.SIDE_LOW, mask, self._recv["low", mask])
         if self.high is not None:
-            b.plane_add(_lib.PLANE_HIGH_OWNED, self._recv["high"][0], mask)
-            b.plane_add(_lib.PLANE_HIGH_HALO, self._recv["high"][1], mask)
+            b.halo_add(_lib.SIDE_HIGH, mask, self._recv["high", mask])
 
     def _migrate(self):
         if self.transport is None:

@@ -80,7 +80,11 @@ extern "C" {
 #define FLOWMPM_PLANE_HIGH_OWNED  2  /* global x = slab_x0 + slab_nx - 1 */
 #define FLOWMPM_PLANE_HIGH_HALO   3  /* global x = slab_x0 + slab_nx     */
 
-/* Component masks for flowmpm_plane_add_i32. */
+/* Sides of a slab for the packed halo exchange. */
+#define FLOWMPM_SIDE_LOW   0   /* planes slab_x0 - 1 and slab_x0                       */
+#define FLOWMPM_SIDE_HIGH  1   /* planes slab_x0 + slab_nx - 1 and slab_x0 + slab_nx   */
+
+/* Component masks for flowmpm_plane_add_i32 and the flowmpm_halo_* calls. */
 #define FLOWMPM_COMP_MOMENTUM 0x7
 #define FLOWMPM_COMP_MASS     0x8
 #define FLOWMPM_COMP_ALL      0xF
@@ -241,6 +245,16 @@ int flowmpm_plane_add_i32(flowmpm_sim *sim, int32_t plane, const void *dev_src,
 /* Writes one boundary plane as {x, y, z, mass} records into a caller's device buffer (send
  * staging). */
 int flowmpm_plane_copy_out(flowmpm_sim *sim, int32_t plane, void *dev_dst);
+
+/* The halo exchange as the step uses it: the two boundary planes of one side (adjacent in
+ * memory, in increasing x; a slab's HIGH pair is its high neighbour's LOW pair) travel with
+ * only the components the merge needs, k = popcount(comp_mask) i32 words per cell in
+ * x, y, z, mass order: 4 bytes per cell after the mass pass, 12 after the momentum pass,
+ * instead of two 16-byte planes each time.  flowmpm_halo_words gives the buffer size in
+ * words; pack writes a send buffer, add merges a received one (wrapping i32 adds). */
+int flowmpm_halo_words(flowmpm_sim *sim, uint32_t comp_mask, int64_t *words);
+int flowmpm_halo_pack(flowmpm_sim *sim, int32_t side, uint32_t comp_mask, void *dev_dst);
+int flowmpm_halo_add(flowmpm_sim *sim, int32_t side, uint32_t comp_mask, const void *dev_src);
 /* Splits the resident particles after g2p: those whose floor(position.x) left
  * [slab_x0, slab_x0 + slab_nx) are removed from the handle and written as packed
  * records (FLOWMPM_MIGRATE_WORDS 32-bit words each: the 23 fields, then the id) into

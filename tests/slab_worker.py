@@ -94,6 +94,28 @@ class OracleSlabBackend:
             if mask & (1 << c):
                 view[:, c] += add[:, c]
 
+    def _pair_view(self, side):
+        per = self.grid[1] * self.grid[2]
+        x = self.x0 - 1 if side == _lib.SIDE_LOW else self.x0 + self.nx - 1
+        return self.orc.cell[x * per:(x + 2) * per]
+
+    @staticmethod
+    def _components(mask):
+        return [c for c in range(4) if mask & (1 << c)]
+
+    def new_halo_buffer(self, mask):
+        return torch.zeros(2 * self.grid[1] * self.grid[2] * len(self._components(mask)), dtype=torch.int32)
+
+    def halo_pack(self, side, mask, out):
+        out.copy_(torch.from_numpy(np.ascontiguousarray(self._pair_view(side)[:, self._components(mask)]).reshape(-1)))
+
+    def halo_add(self, side, mask, src):
+        comps = self._components(mask)
+        view = self._pair_view(side).view(np.uint32)
+        add = src.numpy().reshape(-1, len(comps)).view(np.uint32)
+        for k, c in enumerate(comps):
+            view[:, c] += add[:, k]
+
     def _pack(self, rows):
         r = self.rec[rows]
         out = np.zeros((len(rows), 24), np.float32)

@@ -116,10 +116,12 @@ def test_plane_starts_helpers():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("plane_pairs", [False, True], ids=["planes", "packed_pairs"])
 @pytest.mark.parametrize("algo", [_lib.ALGO_SCATTER, _lib.ALGO_TILED])
-def test_two_slabs_in_one_process_match_single_domain(oracle_binding, algo):
+def test_two_slabs_in_one_process_match_single_domain(oracle_binding, algo, plane_pairs):
     """Drives two slab handles on one GPU with a local 'transport' (device copies), which
-    checks plane add, leaver extraction and arrival insertion against the oracle."""
+    checks the halo merges (whole planes, or the packed plane pairs the step uses), leaver
+    extraction and arrival insertion against the oracle."""
     import torch
     from flow_amd.slab import SlabSimulation
 
@@ -141,6 +143,15 @@ def test_two_slabs_in_one_process_match_single_domain(oracle_binding, algo):
 
     def exchange(mask):
         a, b = sims[0].backend, sims[1].backend
+        if plane_pairs:
+            out_a, out_b = a.new_halo_buffer(mask), b.new_halo_buffer(mask)
+            a.halo_pack(_lib.SIDE_HIGH, mask, out_a)
+            b.halo_pack(_lib.SIDE_LOW, mask, out_b)
+            torch.cuda.synchronize()
+            a.halo_add(_lib.SIDE_HIGH, mask, out_b)
+            b.halo_add(_lib.SIDE_LOW, mask, out_a)
+            torch.cuda.synchronize()
+            return
         bufs = [x.new_plane_buffer(2) for x in (a, b)]
         a.plane_read(_lib.PLANE_HIGH_OWNED, bufs[0][0]); a.plane_read(_lib.PLANE_HIGH_HALO, bufs[0][1])
         b.plane_read(_lib.PLANE_LOW_HALO, bufs[1][0]); b.plane_read(_lib.PLANE_LOW_OWNED, bufs[1][1])
