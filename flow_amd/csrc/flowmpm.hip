@@ -58,9 +58,7 @@ struct flowmpm_sim {
 
     mpm::TiledState tiled{};     // bins, work items (FLOWMPM_ALGO_TILED)
 
-    int *mig_counters = nullptr;   // device scratch for extract_leavers
-    int *mig_lists = nullptr;
-    long long mig_list_cap = 0;
+    mpm::MigrationScratch migration{};   // device scratch of the leaver classification
 
     bool profiling = false;      // the launches being enqueued right now are timed
     int profile_stride = 0;      // 0 off, k: every k-th step of flowmpm_step
@@ -513,8 +511,8 @@ int flowmpm_destroy(flowmpm_sim *s)
     if (s->mass_i) (void)hipFree(s->mass_i);
     if (s->cellf) (void)hipFree(s->cellf);
     if (s->d_modes) (void)hipFree(s->d_modes);
-    if (s->mig_counters) (void)hipFree(s->mig_counters);
-    if (s->mig_lists) (void)hipFree(s->mig_lists);
+    if (s->migration.counters) (void)hipFree(s->migration.counters);
+    if (s->migration.lists) (void)hipFree(s->migration.lists);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return FLOWMPM_OK;
@@ -881,11 +879,44 @@ int flowmpm_extract_leavers(flowmpm_sim *s, const int32_t *plane_starts, int32_t
         return fail(s, FLOWMPM_ERR_INVALID, "bad rank table");
     std::string msg;
     long long new_resident = s->resident;
-    int rc = mpm::extract_leavers(s->store, s->resident, s->params, s->cfg.slab_x0, s->cfg.slab_nx, plane_starts,
-                                  n_ranks, reinterpret_cast<float *>(dev_out), capacity_records, counts,
-                                  &s->mig_counters, &s->mig_lists, &s->mig_list_cap, s->stream, &new_resident, &msg);
+    int rc = mpm::extract_leavers(s->migration, s->store, s->resident, s->cfg.slab_x0, s->cfg.slab_nx, plane_starts,
+                                  n_ranks, reinterpret_cast<float *>(dev_out), capacity_records, counts, s->stream,
+                                  &new_resident, &msg);
     if (rc == 1) return fail(s, FLOWMPM_ERR_HIP, "extract_leavers: " + msg);
     if (rc == 2) return fail(s, FLOWMPM_ERR_CAPACITY, "extract_leavers: " + msg);
+    if (rc) return fail(s, FLOWMPM_ERR_INVALID, "extract_leavers: " + msg);
+    s->resident = s->live = new_resident;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_find_leavers(flowmpm_sim *s, const int32_t *plane_starts, int32_t n_ranks, void *dev_counts)
+{
+    CHECK_SIM(s);
+    if (!s->slab) return fail(s, FLOWMPM_ERR_INVALID, "not a slab handle");
+    if (!plane_starts || n_ranks < 1 || n_ranks > mpm::kMaxRanks || !dev_counts)
+        return fail(s, FLOWMPM_ERR_INVALID, "bad rank table");
+    std::string msg;
+    if (mpm::find_leavers(s->migration, s->store, s->resident, s->cfg.slab_x0, s->cfg.slab_nx, plane_starts, n_ranks,
+                          reinterpret_cast<long long *>(dev_counts), s->stream, &msg))
+        return fail(s, FLOWMPM_ERR_HIP, "find_leavers: " + msg);
+    return FLOWMPM_OK;
+}
+
+int flowmpm_pack_leavers(flowmpm_sim *s, const int64_t *counts, int32_t n_ranks, void *dev_out,
+                         int64_t capacity_records)
+{
+    CHECK_SIM(s);
+    if (!s->slab) return fail(s, FLOWMPM_ERR_INVALID, "not a slab handle");
+    if (!counts || n_ranks < 1 || n_ranks > mpm::kMaxRanks) return fail(s, FLOWMPM_ERR_INVALID, "bad counts");
+    for (int r = 0; r < n_ranks; r++)
+        if (counts[r] < 0 || counts[r] > s->resident) return fail(s, FLOWMPM_ERR_INVALID, "bad counts");
+    std::string msg;
+    long long new_resident = s->resident;
+    int rc = mpm::pack_leavers(s->migration, s->store, s->resident, s->cfg.slab_x0, s->cfg.slab_nx, counts, n_ranks,
+                               reinterpret_cast<float *>(dev_out), capacity_records, s->stream, &new_resident, &msg);
+    if (rc == 1) return fail(s, FLOWMPM_ERR_HIP, "pack_leavers: " + msg);
+    if (rc == 2) return fail(s, FLOWMPM_ERR_CAPACITY, "pack_leavers: " + msg);
+    if (rc) return fail(s, FLOWMPM_ERR_INVALID, "pack_leavers: " + msg);
     s->resident = s->live = new_resident;
     return FLOWMPM_OK;
 }

@@ -100,83 +100,126 @@ unpack_records_kernel(const float *__restrict__ in, StoreSel ss, long long first
     for (int w = 0; w < kRecordWords; w++) st.slot(w)[first_slot + i] = r[w];
 }
 
-// Returns 0 ok, 1 HIP failure, 2 capacity.  One host synchronisation (to learn the
-// leaver counts) per call.
-inline int extract_leavers(StoreSel st, long long n, const Params &P, int x0, int nx,
-                           const int32_t *plane_starts, int n_ranks, float *dev_out,
-                           long long capacity_records, int64_t *counts, int **counters_io,
-                           int **lists_io, long long *list_cap_io, hipStream_t stream,
-                           long long *new_resident, std::string *msg)
+// counters[0 .. n_ranks) as 64-bit words in a caller's device buffer (what the count exchange sends).
+__global__ void export_counts_kernel(const int *__restrict__ counters, int n_ranks, long long *__restrict__ out)
 {
-    (void)P;
-    auto hip_fail = [&](const char *what, hipError_t e) {
-        *msg = std::string(what) + ": " + hipGetErrorString(e);
-        return 1;
-    };
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_ranks) out[r] = counters[r];
+}
+
+struct MigrationScratch {
+    int *counters = nullptr;      // kMaxRanks + 3 device words
+    int *lists = nullptr;         // 5 device arrays of list_cap ints
+    long long list_cap = 0;
+    RankTable table{};            // of the classification in flight
+    long long classified = -1;    // resident count it ran on (-1: none in flight)
+};
+
+inline int migration_reserve(MigrationScratch &M, long long want, std::string *msg)
+{
     hipError_t e;
-    for (int r = 0; r < n_ranks; r++) counts[r] = 0;
-    *new_resident = n;
-    if (n == 0) return 0;
-    const int n_counters = kMaxRanks + 3;
-    if (!*counters_io) {
-        if ((e = hipMalloc(reinterpret_cast<void **>(counters_io), n_counters * sizeof(int))) != hipSuccess)
-            return hip_fail("hipMalloc counters", e);
-    }
-    RankTable rt{};
-    rt.n = n_ranks;
-    for (int r = 0; r <= n_ranks; r++) rt.starts[r] = plane_starts[r];
-    int host_counters[n_counters];
-    long long want = std::max<long long>(*list_cap_io, 4096);
-    for (int attempt = 0; attempt < 2; attempt++) {
-        if (*list_cap_io < want) {
-            if (*lists_io) (void)hipFree(*lists_io);
-            *lists_io = nullptr;
-            if ((e = hipMalloc(reinterpret_cast<void **>(lists_io), (size_t)want * 5 * sizeof(int))) != hipSuccess)
-                return hip_fail("hipMalloc leaver lists", e);
-            *list_cap_io = want;
+    if (!M.counters) {
+        if ((e = hipMalloc(reinterpret_cast<void **>(&M.counters), (kMaxRanks + 3) * sizeof(int))) != hipSuccess) {
+            *msg = std::string("hipMalloc counters: ") + hipGetErrorString(e);
+            return 1;
         }
-        const long long cap = *list_cap_io;
-        int *list_slot = *lists_io, *list_dest = list_slot + cap, *list_k = list_dest + cap;
-        if ((e = hipMemsetAsync(*counters_io, 0, n_counters * sizeof(int), stream)) != hipSuccess)
-            return hip_fail("memset counters", e);
-        hipLaunchKernelGGL(find_leavers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st, n,
-                           x0, nx, rt, *counters_io, list_slot, list_dest, list_k, cap);
-        if ((e = hipGetLastError()) != hipSuccess) return hip_fail("find_leavers", e);
-        if ((e = hipMemcpyAsync(host_counters, *counters_io, n_counters * sizeof(int), hipMemcpyDeviceToHost,
-                                stream)) != hipSuccess)
-            return hip_fail("copy counters", e);
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hip_fail("sync", e);
-        if (host_counters[kMaxRanks] <= cap) break;
-        want = host_counters[kMaxRanks];       // list too small: grow and classify again
     }
-    const int total = host_counters[kMaxRanks];
+    if (M.list_cap < want) {
+        if (M.lists) (void)hipFree(M.lists);
+        M.lists = nullptr;
+        M.list_cap = 0;
+        if ((e = hipMalloc(reinterpret_cast<void **>(&M.lists), (size_t)want * 5 * sizeof(int))) != hipSuccess) {
+            *msg = std::string("hipMalloc leaver lists: ") + hipGetErrorString(e);
+            return 1;
+        }
+        M.list_cap = want;
+    }
+    return 0;
+}
+
+// Enqueues the classification of the n resident particles: leaver counts per destination
+// rank and the leaver list.  Nothing is read back here.  dev_counts (may be null) receives
+// the n_ranks counts as 64-bit words.  Returns 0 ok, 1 HIP failure.
+inline int find_leavers(MigrationScratch &M, StoreSel st, long long n, int x0, int nx, const int32_t *plane_starts,
+                        int n_ranks, long long *dev_counts, hipStream_t stream, std::string *msg)
+{
+    if (migration_reserve(M, std::max<long long>(M.list_cap, 4096), msg)) return 1;
+    M.table = RankTable{};
+    M.table.n = n_ranks;
+    for (int r = 0; r <= n_ranks; r++) M.table.starts[r] = plane_starts[r];
+    hipError_t e = hipMemsetAsync(M.counters, 0, (kMaxRanks + 3) * sizeof(int), stream);
+    if (e != hipSuccess) { *msg = std::string("memset counters: ") + hipGetErrorString(e); return 1; }
+    const long long cap = M.list_cap;
+    if (n > 0)
+        hipLaunchKernelGGL(find_leavers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st, n, x0, nx,
+                           M.table, M.counters, M.lists, M.lists + cap, M.lists + 2 * cap, cap);
+    if (dev_counts)
+        hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kMaxRanks), 0, stream, M.counters, n_ranks, dev_counts);
+    if ((e = hipGetLastError()) != hipSuccess) { *msg = std::string("find_leavers: ") + hipGetErrorString(e); return 1; }
+    M.classified = n;
+    return 0;
+}
+
+// Second half: the caller knows this rank's leaver counts per destination (it read them, or
+// the count matrix they are a row of, from the device).  Packs the leavers grouped by
+// destination into dev_out and fills their slots from the tail.  Returns 0 ok, 1 HIP failure,
+// 2 capacity, 3 call order.
+inline int pack_leavers(MigrationScratch &M, StoreSel st, long long n, int x0, int nx, const int64_t *counts,
+                        int n_ranks, float *dev_out, long long capacity_records, hipStream_t stream,
+                        long long *new_resident, std::string *msg)
+{
+    *new_resident = n;
+    if (M.classified != n || M.table.n != n_ranks) { *msg = "pack_leavers without a matching find_leavers"; return 3; }
+    M.classified = -1;
+    long long total = 0;
+    for (int r = 0; r < n_ranks; r++) total += counts[r];
     if (total == 0) return 0;
-    if (total > capacity_records) {
-        *msg = "leaver buffer too small";
-        return 2;
+    if (total > capacity_records) { *msg = "leaver buffer too small"; return 2; }
+    hipError_t e;
+    if (total > M.list_cap) {
+        // the list overflowed: grow it and classify again (positions have not changed since)
+        if (migration_reserve(M, total, msg)) return 1;
+        if ((e = hipMemsetAsync(M.counters, 0, (kMaxRanks + 3) * sizeof(int), stream)) != hipSuccess) {
+            *msg = std::string("memset counters: ") + hipGetErrorString(e);
+            return 1;
+        }
+        const long long cap = M.list_cap;
+        hipLaunchKernelGGL(find_leavers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st, n, x0, nx,
+                           M.table, M.counters, M.lists, M.lists + cap, M.lists + 2 * cap, cap);
     }
-    const long long cap = *list_cap_io;
-    int *list_slot = *lists_io, *list_dest = list_slot + cap, *list_k = list_dest + cap;
+    const long long cap = M.list_cap;
+    int *list_slot = M.lists, *list_dest = list_slot + cap, *list_k = list_dest + cap;
     int *holes = list_k + cap, *movers = holes + cap;
     RankOffsets ro{};
     long long acc = 0;
-    for (int r = 0; r < n_ranks; r++) {
-        ro.off[r] = acc;
-        counts[r] = host_counters[r];
-        acc += host_counters[r];
-    }
+    for (int r = 0; r < n_ranks; r++) { ro.off[r] = acc; acc += counts[r]; }
     const unsigned tb = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(pack_leavers_kernel, dim3(tb), dim3(256), 0, stream, st, list_slot, list_dest, list_k,
-                       total, ro, dev_out);
+                       (int)total, ro, dev_out);
     const long long new_n = n - total;
-    hipLaunchKernelGGL(find_holes_kernel, dim3(tb), dim3(256), 0, stream, list_slot, total, new_n, *counters_io,
-                       holes);
-    hipLaunchKernelGGL(find_movers_kernel, dim3(tb), dim3(256), 0, stream, st, new_n, n, x0, nx, *counters_io,
-                       movers);
-    hipLaunchKernelGGL(fill_holes_kernel, dim3(tb), dim3(256), 0, stream, st, holes, movers, *counters_io);
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail("compact", e);
+    hipLaunchKernelGGL(find_holes_kernel, dim3(tb), dim3(256), 0, stream, list_slot, (int)total, new_n, M.counters, holes);
+    hipLaunchKernelGGL(find_movers_kernel, dim3(tb), dim3(256), 0, stream, st, new_n, n, x0, nx, M.counters, movers);
+    hipLaunchKernelGGL(fill_holes_kernel, dim3(tb), dim3(256), 0, stream, st, holes, movers, M.counters);
+    if ((e = hipGetLastError()) != hipSuccess) { *msg = std::string("compact: ") + hipGetErrorString(e); return 1; }
     *new_resident = new_n;
     return 0;
+}
+
+// Both halves with one host synchronisation in between (to learn the leaver counts).
+inline int extract_leavers(MigrationScratch &M, StoreSel st, long long n, int x0, int nx, const int32_t *plane_starts,
+                           int n_ranks, float *dev_out, long long capacity_records, int64_t *counts,
+                           hipStream_t stream, long long *new_resident, std::string *msg)
+{
+    for (int r = 0; r < n_ranks; r++) counts[r] = 0;
+    *new_resident = n;
+    if (n == 0) return 0;
+    if (find_leavers(M, st, n, x0, nx, plane_starts, n_ranks, nullptr, stream, msg)) return 1;
+    int host_counters[kMaxRanks + 3];
+    hipError_t e = hipMemcpyAsync(host_counters, M.counters, sizeof host_counters, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { *msg = std::string("read counters: ") + hipGetErrorString(e); return 1; }
+    for (int r = 0; r < n_ranks; r++) counts[r] = host_counters[r];
+    return pack_leavers(M, st, n, x0, nx, counts, n_ranks, dev_out, capacity_records, stream, new_resident, msg);
 }
 
 }  // namespace mpm

@@ -194,6 +194,16 @@ class Handle:
             counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
         return counts
 
+    def find_leavers(self, plane_starts, dev_counts):
+        starts = np.ascontiguousarray(plane_starts, dtype=np.int32)
+        self._chk(self.L.flowmpm_find_leavers(self._h, _ip(starts), starts.shape[0] - 1, ctypes.c_void_p(dev_counts)))
+
+    def pack_leavers(self, counts, dev_out, capacity_records):
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        self._chk(self.L.flowmpm_pack_leavers(
+            self._h, counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), counts.shape[0],
+            ctypes.c_void_p(dev_out), int(capacity_records)))
+
     def insert_arrivals(self, dev_in, count):
         self._chk(self.L.flowmpm_insert_arrivals(self._h, ctypes.c_void_p(dev_in), int(count)))
 

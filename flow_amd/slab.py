@@ -16,8 +16,11 @@ one xGMI link per neighbour; no all-reduce on the data path):
   exchange B  same planes again, the neighbour adds the MOMENTUM components (12 bytes per cell)
   updateGrid  on owned and halo planes alike (redundant on halos, saves a third exchange)
   g2p
-  migrate     particles whose floor(x) left the slab are packed, counted (one small
-              all_gather of the count matrix) and sent straight to their owner
+  migrate     particles whose floor(x) left the slab are counted per destination on the device
+              right after g2p; the counts are exchanged (one small all_gather of the count
+              matrix, read by the host) at the start of the NEXT step, after that step's
+              clearGrid has been enqueued, so that the GPU clears the grid while the host waits
+              for the counts; then the leavers are packed and sent straight to their owner
 
 The grid is fixed-point i32 and the merges are integer adds, so the result is bit-identical
 to the single-GPU grid for any number of slabs; tests assert exactly that.
@@ -111,6 +114,7 @@ class GpuSlabBackend:
         self.max_particles = max_particles
         self._leavers = torch.empty((max(max_particles // 4, 1024), RECORD_WORDS), dtype=torch.float32,
                                     device=self.torch_device)
+        self._counts = None
 
     def set_uniforms(self, **kw):
         self.handle.set_uniforms(**kw)
@@ -152,6 +156,17 @@ class GpuSlabBackend:
         counts = self.handle.extract_leavers(plane_starts, self._leavers.data_ptr(), self._leavers.shape[0])
         return counts, self._leavers[: int(counts.sum())]
 
+    def find_leavers(self, plane_starts):
+        """Enqueues the classification; returns the device tensor the counts will appear in."""
+        if self._counts is None or self._counts.shape[0] != len(plane_starts) - 1:
+            self._counts = torch.zeros(len(plane_starts) - 1, dtype=torch.int64, device=self.torch_device)
+        self.handle.find_leavers(plane_starts, self._counts.data_ptr())
+        return self._counts
+
+    def pack_leavers(self, counts):
+        self.handle.pack_leavers(counts, self._leavers.data_ptr(), self._leavers.shape[0])
+        return self._leavers[: int(np.asarray(counts).sum())]
+
     def new_record_buffer(self, count):
         return torch.empty((count, RECORD_WORDS), dtype=torch.float32, device=self.torch_device)
 
@@ -187,6 +202,7 @@ class SlabSimulation:
         self.high = rank + 1 if rank < world - 1 else None
         b = self.backend
         masks = (_lib.COMP_MASS, _lib.COMP_MOMENTUM)
+        self._pending_counts = None
         self._send = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
         self._recv = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
 
@@ -243,7 +259,10 @@ class SlabSimulation:
         return torch.device("cpu")
 
     def _all_gather_counts(self, counts, dev):
-        t = torch.from_numpy(np.asarray(counts, dtype=np.int64)).to(dev)
+        """counts: numpy array or tensor of `world` int64.  Returns the world x world matrix
+        (row = sender) on the host."""
+        t = counts if torch.is_tensor(counts) else torch.from_numpy(np.asarray(counts, dtype=np.int64))
+        t = t.to(dev)
         out = torch.empty(self.world * self.world, dtype=torch.int64, device=dev)
         self.dist.all_gather_into_tensor(out, t)
         return out.cpu().numpy().reshape(self.world, self.world)
@@ -270,12 +289,20 @@ class SlabSimulation:
         if self.high is not None:
             b.halo_add(_lib.SIDE_HIGH, mask, self._recv["high", mask])
 
-    def _migrate(self):
+    def _begin_migration(self):
         if self.transport is None:
             return
+        self._pending_counts = self.backend.find_leavers(self.plane_starts)
+
+    def _finish_migration(self):
+        """Completes the migration begun after the last g2p (a no-op when none is pending)."""
+        counts_dev, self._pending_counts = self._pending_counts, None
+        if counts_dev is None:
+            return
         b = self.backend
-        counts, packed = b.extract_leavers(self.plane_starts)
-        matrix = self._all_gather_counts(counts, self._comm_device())
+        matrix = self._all_gather_counts(counts_dev, self._comm_device())
+        counts = matrix[self.rank]
+        packed = b.pack_leavers(counts)
         if not matrix.any():
             return
         offs = np.concatenate([[0], np.cumsum(counts)])
@@ -297,23 +324,28 @@ class SlabSimulation:
     def step(self):
         b = self.backend
         p2g = self.p2g_kernels
-        b.run_kernel(_lib.KERNEL_CLEAR_GRID)
+        b.run_kernel(_lib.KERNEL_CLEAR_GRID)      # touches no particle: runs while the counts travel
+        self._finish_migration()
         b.run_kernel(p2g[0])
         self._exchange_planes(_lib.COMP_MASS)
         b.run_kernel(p2g[1])
         self._exchange_planes(_lib.COMP_MOMENTUM)
         b.run_kernel(_lib.KERNEL_UPDATE_GRID)
         b.run_kernel(_lib.KERNEL_G2P)
-        self._migrate()
+        self._begin_migration()
 
     def resident(self):
+        self._finish_migration()
         return self.backend.resident()
 
     def synchronize(self):
+        """Also completes the migration of the last step (a collective: every rank calls it)."""
+        self._finish_migration()
         self.backend.synchronize()
 
     def download(self):
         """(records, global ids) of the particles resident on this rank."""
+        self._finish_migration()
         return self.backend.download()
 
     def close(self):

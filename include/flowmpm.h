@@ -263,6 +263,15 @@ int flowmpm_halo_add(flowmpm_sim *sim, int32_t side, uint32_t comp_mask, const v
 #define FLOWMPM_MIGRATE_WORDS 24
 int flowmpm_extract_leavers(flowmpm_sim *sim, const int32_t *plane_starts, int32_t n_ranks,
                             void *dev_out, int64_t capacity_records, int64_t *counts);
+/* The same in two halves, so that the caller can take the counts through its own count
+ * exchange and keep the stream busy meanwhile.  flowmpm_find_leavers only enqueues the
+ * classification; the n_ranks leaver counts appear as int64 words in `dev_counts` (device
+ * memory of the caller) in stream order.  flowmpm_pack_leavers takes those counts back from
+ * the caller (host memory) once it has read them, packs the records and compacts the store.
+ * No step may run between the two calls. */
+int flowmpm_find_leavers(flowmpm_sim *sim, const int32_t *plane_starts, int32_t n_ranks, void *dev_counts);
+int flowmpm_pack_leavers(flowmpm_sim *sim, const int64_t *counts, int32_t n_ranks, void *dev_out,
+                         int64_t capacity_records);
 /* Appends packed records that arrived from other ranks. */
 int flowmpm_insert_arrivals(flowmpm_sim *sim, const void *dev_in, int64_t count);
 

@@ -127,6 +127,19 @@ class OracleSlabBackend:
         out[:, 23] = self.ids[rows].view(np.float32)
         return out
 
+    def find_leavers(self, plane_starts):
+        self._plane_starts = list(plane_starts)
+        ix = np.trunc(self.rec[:, 0]).astype(np.int64)
+        leaving = (ix < self.x0) | (ix >= self.x0 + self.nx)
+        world = len(plane_starts) - 1
+        dest = np.clip(np.searchsorted(np.asarray(plane_starts), ix, side="right") - 1, 0, world - 1)
+        return torch.from_numpy(np.bincount(dest[leaving], minlength=world).astype(np.int64))
+
+    def pack_leavers(self, counts):
+        got, packed = self.extract_leavers(self._plane_starts)
+        assert np.array_equal(got, np.asarray(counts))
+        return packed
+
     def extract_leavers(self, plane_starts):
         ix = np.trunc(self.rec[:, 0]).astype(np.int64)
         leaving = (ix < self.x0) | (ix >= self.x0 + self.nx)
