@@ -16,8 +16,8 @@
  * must agree bit for bit, and (b) implementation-independent properties of the
  * reference's arithmetic (see tests/test_oracle.py).
  *
- * The mode branches of g2p (orc_g2p_modes) are restated by this C file only (no numpy twin).
- * Two of its expressions depend on how three.js types a binary operator whose operands differ
+ * The mode branches of g2p (orc_g2p_modes) have their numpy twin too (mpm_numpy.g2p_modes).
+ * Two of their expressions depend on how three.js types a binary operator whose operands differ
  * (`gridSize.sub(1)` at SIM:490 and `gridSize.x.mul(0.1)` at SIM:1481): this restatement
  * follows three.js's OperatorNode, which takes the left operand's type unless the right one
  * is a longer vector and converts both operands to it.  For SIM:490 both readings agree; for

@@ -326,3 +326,31 @@ def test_hidden_particles_are_parked_at_the_x_faces(oracle_binding):
     assert np.allclose(got[sel, 4], pull[sel], atol=0.011)
     assert (np.sign(got[sel, 4]) == np.sign(pull[sel])).all()
     assert np.allclose(got[~hidden & inner, 4], 0.25, atol=0.02)   # visible particles follow the grid
+
+
+@pytest.mark.parametrize("name", mode_cases.ALL_CASES)
+def test_numpy_twin_agrees_with_c_on_every_mode_case(oracle_binding, name):
+    """Two restatements of SIM:431-1536 that share no code (oracle/mpm_oracle.c and
+    oracle/mpm_numpy.py) must agree bit for bit, starting from a grid with flow on it."""
+    from oracle import mpm_numpy
+    ob = oracle_binding
+    n = 3000
+    uni, fields = mode_cases.case(name)
+    kw = dict(BASE, **uni)
+    rec = mode_cases.particles(n, seed=17)
+    orc = ob.Oracle(mode_cases.GRID)
+    u = ob.make_uniforms(mode_cases.GRID, n, **kw)
+    orc.clear_grid()
+    orc.p2g1(rec, u)
+    orc.p2g2(rec, u)
+    orc.update_grid(u)
+    want, got = rec.copy(), rec.copy()
+    orc.g2p_modes(want, u, mode_cases.fill(ob.ModeUniforms, fields))
+    mpm_numpy.g2p_modes(got, orc.cellf, mode_cases.GRID, n, fields, dt=kw["dt"], noise=kw["noise"],
+                        time=kw["time"], cursor=kw.get("cursor_interaction", 0),
+                        ray_dir=kw.get("mouse_ray_direction", (0, 0, 0)),
+                        ray_origin=kw.get("mouse_ray_origin", (0, 0, 0)),
+                        mouse_force=kw.get("mouse_force", (0, 0, 0)), grid_mode=kw.get("grid_mode", 0),
+                        front_gravity_mode=kw.get("front_gravity_mode", 0),
+                        hide_percentage=kw.get("hide_percentage", 0.0))
+    assert_bits_equal(got, want, name)
