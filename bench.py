@@ -196,6 +196,10 @@ def run_single(args):
     algo = {"tiled": _lib.ALGO_TILED, "tiled_unfused": _lib.ALGO_TILED_UNFUSED, "scatter": _lib.ALGO_SCATTER}[args.algorithm]
     h = flow_amd.Handle(grid, n, device=0, algorithm=algo, rebin_interval=args.rebin_interval)
     rec = make_particles(args.scene, n, grid, seed)
+    max_per_cell = None
+    if args.scene == "dam_break":        # how crowded the column starts out
+        ix = np.floor(rec[:, 0:3]).astype(np.int64)
+        max_per_cell = int(np.bincount((ix[:, 0] * grid[1] + ix[:, 1]) * grid[2] + ix[:, 2]).max())
     h.upload_particles(rec)
     if args.mode != "chaos":
         mode_uni, mode_record = mode_setup(args.mode, grid, n)
@@ -245,7 +249,8 @@ def run_single(args):
                    "algorithm": args.algorithm,
                    "rebin_interval": args.rebin_interval, "timing_stride": args.timing_stride, "dt": 0.1,
                    "noise": 0.0,
-                   "cursor_interaction": 1 if args.scene == "dam_break" else 0},
+                   "cursor_interaction": 1 if args.scene == "dam_break" else 0,
+                   "max_particles_per_cell_at_start": max_per_cell},
         "roofline": roof,
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes,
                           "achieved_GBs": round(step_bytes / (elapsed / args.steps) / 1e9, 1),

@@ -38,7 +38,7 @@ EXPORTS = (
     "flowmpm_set_profiling", "flowmpm_get_timings", "flowmpm_reset_timings", "flowmpm_plane_bytes",
     "flowmpm_plane_add_i32", "flowmpm_plane_copy_out", "flowmpm_extract_leavers",
     "flowmpm_insert_arrivals", "flowmpm_set_mode_uniforms", "flowmpm_halo_words", "flowmpm_halo_pack",
-    "flowmpm_halo_add", "flowmpm_find_leavers", "flowmpm_pack_leavers",
+    "flowmpm_halo_add", "flowmpm_find_leavers", "flowmpm_pack_leavers", "flowmpm_grid_sums",
 )
 
 
@@ -158,6 +158,7 @@ def load():
         "flowmpm_halo_words": ([vp, u32, i64p], ctypes.c_int),
         "flowmpm_halo_pack": ([vp, i32, u32, vp], ctypes.c_int),
         "flowmpm_halo_add": ([vp, i32, u32, vp], ctypes.c_int),
+        "flowmpm_grid_sums": ([vp, i64p], ctypes.c_int),
         "flowmpm_find_leavers": ([vp, ip, i32, vp], ctypes.c_int),
         "flowmpm_pack_leavers": ([vp, i64p, i32, vp, i64], ctypes.c_int),
     }

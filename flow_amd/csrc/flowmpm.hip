@@ -820,6 +820,28 @@ int flowmpm_plane_copy_out(flowmpm_sim *s, int32_t plane, void *dev_dst)
     return launch_check(s, "plane_copy_out");
 }
 
+int flowmpm_grid_sums(flowmpm_sim *s, int64_t *sums)
+{
+    CHECK_SIM(s);
+    if (!sums) return fail(s, FLOWMPM_ERR_INVALID, "null output");
+    const long long plane = (long long)s->cfg.grid_y * s->cfg.grid_z;
+    const long long first = s->slab ? plane : 0;                       // skip the low halo plane
+    const long long cells = s->slab ? (long long)s->cfg.slab_nx * plane : s->local_cells;
+    unsigned long long *d = nullptr;
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&d), 4 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), s->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mpm::grid_sums_kernel, dim3(1024), dim3(256), 0, s->stream, s->cell + first,
+                           s->mass_i + first, cells, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(sums, d, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("grid_sums: ") + hipGetErrorString(e));
+    return FLOWMPM_OK;
+}
+
 // First cell and cell count of the two adjacent boundary planes of one side.
 static int halo_pair(flowmpm_sim *s, int32_t side, uint32_t comp_mask, long long *first, long long *cells, int *k)
 {

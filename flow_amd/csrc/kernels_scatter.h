@@ -352,6 +352,28 @@ halo_add_kernel(int4 *__restrict__ dst, int *__restrict__ dst_mass, const int *_
     if (mask & 8u) dst_mass[i] = (int)((unsigned)dst_mass[i] + (unsigned)*p);
 }
 
+// 64-bit sums of the four fixed-point components over `cells` consecutive cells (conservation
+// tracking: the grid mass is an integer sum that the step conserves exactly).  out[0..3] must
+// be zero on entry.
+__global__ void __launch_bounds__(256)
+grid_sums_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass, long long cells,
+                 unsigned long long *__restrict__ out)
+{
+    long long acc[4] = {0, 0, 0, 0};
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
+        int4 c = cell[i];
+        acc[0] += c.x; acc[1] += c.y; acc[2] += c.z; acc[3] += mass[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        long long v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(out + k, (unsigned long long)v);
+    }
+}
+
 // The reference's cell records {x, y, z, mass} of `cells` consecutive cells, assembled from
 // the device layout (downloads, halo-plane send staging).
 __global__ void __launch_bounds__(256)

@@ -147,6 +147,12 @@ class Handle:
         self._chk(self.L.flowmpm_download_grid_f32(self._h, _fp(out), cells))
         return out
 
+    def grid_sums(self):
+        """int64 sums of the owned fixed-point grid: [x, y, z, mass]."""
+        out = np.zeros(4, dtype=np.int64)
+        self._chk(self.L.flowmpm_grid_sums(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        return out
+
     def set_profiling(self, every_nth_step):
         """0 / False: off; 1 / True: every launch; k: the launches of every k-th step()."""
         self._chk(self.L.flowmpm_set_profiling(self._h, int(every_nth_step)))

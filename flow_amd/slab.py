@@ -170,6 +170,9 @@ class GpuSlabBackend:
     def new_record_buffer(self, count):
         return torch.empty((count, RECORD_WORDS), dtype=torch.float32, device=self.torch_device)
 
+    def grid_sums(self):
+        return self.handle.grid_sums()
+
     def insert_arrivals(self, records):
         self.handle.insert_arrivals(records.data_ptr(), records.shape[0])
 
@@ -342,6 +345,19 @@ class SlabSimulation:
         """Also completes the migration of the last step (a collective: every rank calls it)."""
         self._finish_migration()
         self.backend.synchronize()
+
+    def conservation(self):
+        """Global [grid x, y, z momentum words, grid mass words, particle count] as int64: one
+        small all-reduce, for a reporting interval, not for every step.  The grid sums are
+        those of the last step's p2g; the mass sum is exact and independent of the number of
+        slabs."""
+        self._finish_migration()
+        local = np.concatenate([self.backend.grid_sums(), [self.backend.resident()]]).astype(np.int64)
+        if self.transport is None:
+            return local
+        t = torch.from_numpy(local).to(self._comm_device())
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
 
     def download(self):
         """(records, global ids) of the particles resident on this rank."""

@@ -222,6 +222,12 @@ int flowmpm_get_local_grid(flowmpm_sim *sim, int32_t *x_first, int32_t *x_planes
 int flowmpm_download_grid_i32(flowmpm_sim *sim, int32_t *out, int64_t capacity_cells);
 int flowmpm_download_grid_f32(flowmpm_sim *sim, float *out, int64_t capacity_cells);
 
+/* Conservation tracking: the 64-bit sums of the fixed-point grid's x, y, z and mass words over
+ * the cells this handle owns (halo planes excluded), computed on the device.  After p2g the
+ * mass sum is an integer the rest of the step conserves exactly; summed over the slabs of a
+ * decomposed run it equals the single-GPU value. */
+int flowmpm_grid_sums(flowmpm_sim *sim, int64_t sums[4]);
+
 /* Per-kernel device timing: HIP events attached to the kernel dispatches on the handle's
  * stream (start and end timestamps of the kernel itself).  every_nth_step = 0 switches it
  * off, 1 times every launch, k > 1 times the launches of every k-th step of flowmpm_step

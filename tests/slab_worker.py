@@ -166,6 +166,10 @@ class OracleSlabBackend:
         self.rec = np.concatenate([self.rec, r])
         self.ids = np.concatenate([self.ids, np.ascontiguousarray(p[:, 23]).view(np.int32)])
 
+    def grid_sums(self):
+        per = self.grid[1] * self.grid[2]
+        return self.orc.cell[self.x0 * per:(self.x0 + self.nx) * per].astype(np.int64).sum(axis=0)
+
     def owned_grid(self):
         per = self.grid[1] * self.grid[2]
         return (self.orc.cell[self.x0 * per:(self.x0 + self.nx) * per].copy(),
@@ -222,6 +226,7 @@ def main():
         sim.set_uniforms(**dict(DEFAULT_UNIFORMS, time=0.25 * k, **mode_uni))
         sim.step()
     sim.synchronize()
+    totals = sim.conservation()
     out_rec, out_ids = sim.download()
     if args.backend == "oracle":
         cell, cellf = sim.backend.owned_grid()
@@ -230,7 +235,7 @@ def main():
         cell = sim.backend.handle.download_grid_i32()[per:(nx + 1) * per]
         cellf = sim.backend.handle.download_grid_f32()[per:(nx + 1) * per]
     np.savez(os.path.join(args.out, "rank%d.npz" % rank), rec=out_rec, ids=out_ids, cell=cell, cellf=cellf,
-             starts=np.asarray(starts))
+             starts=np.asarray(starts), totals=totals)
     sim.close()
     dist.barrier()
     dist.destroy_process_group()

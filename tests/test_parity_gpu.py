@@ -410,3 +410,14 @@ def test_long_run_conservation_tracking():
         assert np.allclose(np.where(zeroed, fixed, back), fixed, rtol=1e-5, atol=1e-6)
     assert max(history) - min(history) < 40 * n
     h.close()
+
+
+def test_grid_sums_match_the_downloaded_grid(oracle_binding):
+    grid, n = (24, 16, 12), 4000
+    rec = moving_particles(n, grid, seed=77, vel=2.0)
+    h = _handle(grid, rec, _lib.ALGO_TILED)
+    h.step(3, 0.1)
+    cell = h.download_grid_i32().astype(np.int64)
+    assert np.array_equal(h.grid_sums(), cell.sum(axis=0))
+    assert abs(int(h.grid_sums()[3]) - n * 10_000_000) <= 27 * n      # < 1 unit lost per stencil cell
+    h.close()

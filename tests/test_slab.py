@@ -54,6 +54,8 @@ def _check_against_single_domain(out, world, rec, orc, grid):
         ix = np.floor(d["rec"][:, 0]).astype(int)
         assert ((ix >= x0) & (ix < x1)).all(), "rank %d holds a particle outside its slab" % r
         assert np.array_equal(d["cell"], orc.cell[x0 * per:x1 * per]), "fixed-point grid of rank %d" % r
+        want_totals = np.concatenate([orc.cell.astype(np.int64).sum(axis=0), [rec.shape[0]]])
+        assert np.array_equal(d["totals"], want_totals), "conservation sums on rank %d" % r
         assert_bits_equal(d["cellf"], orc.cellf[x0 * per:x1 * per], "float grid of rank %d" % r)
         n = rec.shape[0]
         first_owner = np.arange(n)[d["ids"]] * world // n
