@@ -430,8 +430,9 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         return fail(nullptr, FLOWMPM_ERR_INVALID, "grid must be at least 6 cells on every axis");
     if ((long long)c.grid_x * c.grid_y * c.grid_z > 2147483647LL / 4)
         return fail(nullptr, FLOWMPM_ERR_INVALID, "grid too large for 32-bit cell indexing");
-    if (c.max_particles < 0 || c.max_particles > 2147483647LL)
-        return fail(nullptr, FLOWMPM_ERR_INVALID, "max_particles out of range");
+    // slot arrays are addressed with 32-bit byte offsets (mpm::Column)
+    if (c.max_particles < 0 || c.max_particles > mpm::kMaxCapacity - 64)
+        return fail(nullptr, FLOWMPM_ERR_INVALID, "max_particles out of range (at most 2^30 - 64)");
     if (c.algorithm != FLOWMPM_ALGO_SCATTER && c.algorithm != FLOWMPM_ALGO_TILED &&
         c.algorithm != FLOWMPM_ALGO_TILED_UNFUSED)
         return fail(nullptr, FLOWMPM_ERR_INVALID, "unknown algorithm");

@@ -10,11 +10,30 @@
 
 namespace mpm {
 
+// One slot array of the store, indexed by particle slot.  The byte offset is formed in 32 bits
+// (capacity is limited to 2^30 elements for that), so an access is "uniform 64-bit base +
+// 32-bit lane offset": the global_load / global_store form with a scalar base register, and
+// no 64-bit address arithmetic per lane and access.
+template <typename T>
+struct Column {
+    T *p;
+    __device__ __forceinline__ T &operator[](unsigned i) const
+    {
+        return *reinterpret_cast<T *>(reinterpret_cast<char *>(p) + (size_t)(i << 2));
+    }
+    __device__ __forceinline__ T *operator+(unsigned i) const { return &(*this)[i]; }
+};
+
+constexpr long long kMaxCapacity = 1LL << 30;
+
 struct Store {
     float *base;        // kNumSlots arrays of `capacity` elements, slot-major
     long long capacity;
-    __device__ __host__ __forceinline__ float *slot(int k) const { return base + (long long)k * capacity; }
-    __device__ __host__ __forceinline__ int *ids() const { return reinterpret_cast<int *>(slot(kId)); }
+    __device__ __forceinline__ Column<float> slot(int k) const { return Column<float>{base + (long long)k * capacity}; }
+    __device__ __forceinline__ Column<int> ids() const
+    {
+        return Column<int>{reinterpret_cast<int *>(base + (long long)kId * capacity)};
+    }
 };
 
 // The two particle stores of a handle and the device word that says which one is current.
@@ -127,7 +146,7 @@ p2g2_scatter_kernel(StoreSel ss, long long n, FixedGrid g, Params P)
                 density = density + decode_fixed(m) * weight;
             }
         }
-    float *dens = st.slot(kDensity);
+    const Column<float> dens = st.slot(kDensity);
     dens[j] = dens[j] * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
 
     Eq16 e = p2g2_stress(density, C, P);

@@ -502,7 +502,7 @@ p2g2_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     }
     __syncthreads();
 
-    float *dens = st.slot(kDensity);
+    const Column<float> dens = st.slot(kDensity);
     for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
         float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
         float C[9];
@@ -666,7 +666,7 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         mass_f[a] = decode_fixed((c >= 0) ? g.mass[c] : 0);
     }
     __syncthreads();
-    float *dens = st.slot(kDensity);
+    const Column<float> dens = st.slot(kDensity);
     // Software pipeline: the next particle's 15 loads are issued before this particle's LDS
     // atomics and density store, so an iteration never starts by waiting on memory.
     float in[15];

@@ -102,7 +102,7 @@ typedef struct {
     int32_t rebin_interval;           /* tiled: re-bin particles at least every k steps (>= 1); the
                                        * device re-bins earlier when too many particles have left
                                        * their tile's neighbourhood.  Never affects results. */
-    int64_t max_particles;            /* conf.maxParticles, src/conf.js:8 */
+    int64_t max_particles;            /* conf.maxParticles, src/conf.js:8; at most 2^30 - 64 */
     void   *stream;                   /* hipStream_t to enqueue on when external_stream != 0
                                          (NULL is then the device's default stream) */
     int32_t external_stream;          /* 0: the handle creates and owns its stream */
