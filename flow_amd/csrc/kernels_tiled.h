@@ -99,6 +99,9 @@ struct TiledState {
     Stragglers stragglers{nullptr, nullptr};
 };
 
+// Two floats that one packed instruction (v_pk_mul_f32, v_pk_add_f32) operates on.
+typedef float Float2v __attribute__((ext_vector_type(2)));
+
 struct TileDims { int tiles_x, tiles_y, tiles_z; };
 
 // What a tiled particle kernel needs to find its particles.
@@ -707,18 +710,30 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 
 // ---- g2p (SIM:431-1536; MODES as in g2p_gather_kernel) ------------------------------
 
+// The 27-cell gather of g2p (SIM:1322-1352): v += w*g and B += (w*g) (x) dist.  The sums are
+// kept as two-float vectors -- (B0,B1), (B3,B4), (B6,B7) share the factor pair (w*g.x, w*g.y),
+// (B2,B5) shares w*g.z against (dx,dy) -- so that one packed instruction does two of the
+// reference's multiplications or additions; each value still sees exactly the reference's
+// operations in the reference's order.
 template <bool INSIDE>
 __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid, int abase,
                                            const float4 *__restrict__ cellf, const Params &P, Vec3 &v, float B[9])
 {
+    Float2v B01 = {B[0], B[1]}, B34 = {B[3], B[4]}, B67 = {B[6], B[7]}, B25 = {B[2], B[5]};
+    float B8 = B[8];
+    Float2v vxy = {v.x, v.y};
+    float vz = v.z;
 #pragma unroll
     for (int gx = 0; gx < 3; gx++)
 #pragma unroll
         for (int gy = 0; gy < 3; gy++) {
-            float wxy = s.wx[gx] * s.wy[gy];
+            const float wxy = s.wx[gx] * s.wy[gy];
+            const Float2v dxy = {s.dx[gx], s.dy[gy]};
+            const Float2v w01 = wxy * Float2v{s.wz[0], s.wz[1]};
+            const float w2 = wxy * s.wz[2];
 #pragma unroll
             for (int gz = 0; gz < 3; gz++) {
-                float weight = wxy * s.wz[gz];
+                const float weight = gz == 0 ? w01.x : gz == 1 ? w01.y : w2;
                 float4 f;
                 if (INSIDE) {
                     f = grid[abase + arena_index(gx, gy, gz)];
@@ -731,12 +746,16 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     f = (c >= 0) ? cellf[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
-                float wvx = f.x * weight, wvy = f.y * weight, wvz = f.z * weight;
-                float dx = s.dx[gx], dy = s.dy[gy], dz = s.dz[gz];
-                B[0] = B[0] + wvx * dx; B[1] = B[1] + wvy * dx; B[2] = B[2] + wvz * dx;
-                B[3] = B[3] + wvx * dy; B[4] = B[4] + wvy * dy; B[5] = B[5] + wvz * dy;
-                B[6] = B[6] + wvx * dz; B[7] = B[7] + wvy * dz; B[8] = B[8] + wvz * dz;
-                v.x = v.x + wvx; v.y = v.y + wvy; v.z = v.z + wvz;
+                const Float2v wvxy = Float2v{f.x, f.y} * weight;
+                const float wvz = f.z * weight;
+                const float dz = s.dz[gz];
+                B01 = B01 + wvxy * dxy.x;
+                B34 = B34 + wvxy * dxy.y;
+                B67 = B67 + wvxy * dz;
+                B25 = B25 + wvz * dxy;
+                B8 = B8 + wvz * dz;
+                vxy = vxy + wvxy;
+                vz = vz + wvz;
             }
 #if FLOWMPM_SLAB_FENCE == 1
             // keep the compiler from hoisting all 27 arena reads (108 VGPRs) to the top
@@ -745,6 +764,9 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
             if (INSIDE) __builtin_amdgcn_sched_barrier(0);
 #endif
         }
+    B[0] = B01.x; B[1] = B01.y; B[3] = B34.x; B[4] = B34.y; B[6] = B67.x; B[7] = B67.y;
+    B[2] = B25.x; B[5] = B25.y; B[8] = B8;
+    v.x = vxy.x; v.y = vxy.y; v.z = vz;
 }
 
 template <bool MODES>
