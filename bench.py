@@ -46,6 +46,8 @@ def parse_args():
                     help="display mode whose g2p forces run in the timed steps (N=1 only)")
     ap.add_argument("--timing-stride", type=int, default=8,
                     help="HIP events on the kernels of every k-th timed step (1 = every step)")
+    ap.add_argument("--noise", type=float, default=0.0,
+                    help="the noise uniform (conf.js default: 1.0); the noise field is computed either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
@@ -55,12 +57,13 @@ def parse_args():
     return ap.parse_args()
 
 
-def scene_uniforms(n_particles, grid_cells, scene):
+def scene_uniforms(n_particles, grid_cells, scene, noise=0.0):
     """Benchmark uniforms: rest density set so the mean density is about the rest density
-    (the ellipsoid fills 0.268 of the box), dt = 0.1, no noise, no mouse force."""
+    (the ellipsoid fills 0.268 of the box), dt = 0.1, no mouse force.  `noise` scales the
+    noise force; the kernel evaluates the noise field whatever its value."""
     fill = 0.268 if scene == "ellipsoid" else 0.25
     return dict(dt=0.1, stiffness=3.0, rest_density=n_particles / (fill * grid_cells),
-                dynamic_viscosity=0.1, noise=0.0, time=0.0)
+                dynamic_viscosity=0.1, noise=noise, time=0.0)
 
 
 def mode_setup(name, grid, n):
@@ -192,7 +195,7 @@ def run_single(args):
     grid = tuple(int(x) for x in args.grid.split(",")) if args.grid else (256, 256, 256)
     cells = grid[0] * grid[1] * grid[2]
     seed = 0xF10E5EED + 3
-    uniforms = scene_uniforms(n, cells, args.scene)
+    uniforms = scene_uniforms(n, cells, args.scene, args.noise)
     algo = {"tiled": _lib.ALGO_TILED, "tiled_unfused": _lib.ALGO_TILED_UNFUSED, "scatter": _lib.ALGO_SCATTER}[args.algorithm]
     h = flow_amd.Handle(grid, n, device=0, algorithm=algo, rebin_interval=args.rebin_interval)
     rec = make_particles(args.scene, n, grid, seed)
@@ -248,7 +251,7 @@ def run_single(args):
                    "scene": args.scene, "mode": args.mode, "particles": n, "grid": list(grid),
                    "algorithm": args.algorithm,
                    "rebin_interval": args.rebin_interval, "timing_stride": args.timing_stride, "dt": 0.1,
-                   "noise": 0.0,
+                   "noise": args.noise,
                    "cursor_interaction": 1 if args.scene == "dam_break" else 0,
                    "max_particles_per_cell_at_start": max_per_cell},
         "roofline": roof,
@@ -285,7 +288,7 @@ def run_distributed(args):
     grid = (args.slab_x_per_gpu * world, args.slab_yz, args.slab_yz)
     cells = grid[0] * grid[1] * grid[2]
     seed = 0xF10E5EED + 4
-    uniforms = scene_uniforms(n_total, cells, args.scene)
+    uniforms = scene_uniforms(n_total, cells, args.scene, args.noise)
     algo = {"tiled": _lib.ALGO_TILED, "tiled_unfused": _lib.ALGO_TILED_UNFUSED, "scatter": _lib.ALGO_SCATTER}[args.algorithm]
 
     # Every rank generates the id range [rank*n_per, (rank+1)*n_per) of the global scene; the
@@ -301,6 +304,11 @@ def run_distributed(args):
     for _ in range(args.warmup):
         sim.step()
     sim.synchronize()
+    handle = getattr(sim.backend, "handle", None)
+    n_start = sim.resident()
+    if handle is not None:
+        handle.set_profiling(args.timing_stride)
+        handle.reset_timings()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -318,6 +326,13 @@ def run_distributed(args):
     line = None
     if rank == 0:
         per_rank = [int(g.item()) for g in gathered]
+        # rank 0's own launches (HIP events on its stream, sampled like the single-GPU run),
+        # against the algorithmic bytes of the particles and cells that rank holds
+        roof, per_kernel = None, None
+        if handle is not None:
+            local_cells = (starts[1] - starts[0]) * grid[1] * grid[2]
+            roof, per_kernel = roofline_of(handle.timings(), (n_start + per_rank[0]) // 2, local_cells)
+            roof["scope"] = "rank 0: %d planes, about %d particles" % (starts[1] - starts[0], (n_start + per_rank[0]) // 2)
         line = {
             "metric": "particle-substeps/sec", "value": n_total * args.steps / elapsed,
             "unit": "particle-substeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -327,9 +342,10 @@ def run_distributed(args):
                                    % (n_total, grid[0], grid[1], grid[2], world, world, n_per),
                        "transport": args.dist_backend,
                        "scene": args.scene, "particles": n_total, "grid": list(grid), "algorithm": args.algorithm,
+                       "noise": args.noise, "timing_stride": args.timing_stride,
                        "rebin_interval": args.rebin_interval, "parallelism": "slab%d" % world,
                        "plane_starts": [int(s) for s in starts], "resident_per_rank_end": per_rank},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roof, "kernels": per_kernel, "cpu_baseline": None,
         }
     dist.destroy_process_group()
     return line

@@ -570,6 +570,9 @@ int flowmpm_set_mode_uniforms(flowmpm_sim *s, const flowmpm_mode_uniforms *m)
 int flowmpm_run_kernel(flowmpm_sim *s, int32_t kernel_id)
 {
     CHECK_SIM(s);
+    // clearGrid opens a step: the profiling stride counts steps here as it does in flowmpm_step
+    if (kernel_id == FLOWMPM_KERNEL_CLEAR_GRID)
+        s->profiling = s->profile_stride > 0 && (s->profile_step++ % s->profile_stride) == 0;
     switch (kernel_id) {
     case FLOWMPM_KERNEL_CLEAR_GRID: return stage_clear_grid(s);
     case FLOWMPM_KERNEL_P2G1: return stage_p2g1(s);

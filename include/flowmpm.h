@@ -232,8 +232,9 @@ int flowmpm_grid_sums(flowmpm_sim *sim, int64_t sums[4]);
  * stream (start and end timestamps of the kernel itself).  every_nth_step = 0 switches it
  * off, 1 times every launch, k > 1 times the launches of every k-th step of flowmpm_step
  * (a timed dispatch costs the queue a few microseconds; sampling keeps a timed run within a
- * fraction of a percent of an untimed one).  flowmpm_run_kernel launches are timed whenever
- * the value is not 0. */
+ * fraction of a percent of an untimed one).  For flowmpm_run_kernel a step begins at each
+ * FLOWMPM_KERNEL_CLEAR_GRID: the launches from the k-th such call up to the next one are
+ * timed. */
 int flowmpm_set_profiling(flowmpm_sim *sim, int32_t every_nth_step);
 int flowmpm_get_timings(flowmpm_sim *sim, flowmpm_timings *out);
 int flowmpm_reset_timings(flowmpm_sim *sim);
