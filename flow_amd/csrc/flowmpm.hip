@@ -51,6 +51,10 @@ struct flowmpm_sim {
     int drift_divisor = 256;      // re-bin when (particles outside their arena) * divisor > particles
     int4 *cell = nullptr;        // momentum words (word 3 unused on the device)
     int *mass_i = nullptr;       // mass words, one per cell
+    // The float grid is non-zero only where this buffer is positive: the mass words of the step
+    // whose updateGrid last wrote it.  Either mass_i or mass_spare.
+    int *mass_of_cellf = nullptr;
+    int *mass_spare = nullptr;
     mpm::FixedGrid fixed() const { return mpm::FixedGrid{reinterpret_cast<int *>(cell), mass_i}; }
     float4 *cellf = nullptr;
     long long local_cells = 0;
@@ -169,14 +173,23 @@ int launch_check(flowmpm_sim *s, const char *what)
     return FLOWMPM_OK;
 }
 
-int stage_clear_grid(flowmpm_sim *s)
+// float_grid = false: the fixed-point grid only.  The mass words that describe the float grid
+// must survive until updateGrid has used them, so the step accumulates into the other buffer.
+int stage_clear_grid(flowmpm_sim *s, bool float_grid = true)
 {
     TimedLaunch t;
     int rc = timing_events(s, FLOWMPM_KERNEL_CLEAR_GRID, &t);
     if (rc) return rc;
     unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
-    hipExtLaunchKernelGGL(mpm::clear_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
-                          s->cell, s->mass_i, s->cellf, s->local_cells);
+    if (float_grid) {
+        hipExtLaunchKernelGGL(mpm::clear_grid_kernel<true>, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
+                              s->cell, s->mass_i, s->cellf, s->mass_spare, s->local_cells);
+        s->mass_of_cellf = s->mass_i;       // all zero, like the float grid
+    } else {
+        if (s->mass_i == s->mass_of_cellf) std::swap(s->mass_i, s->mass_spare);
+        hipExtLaunchKernelGGL(mpm::clear_grid_kernel<false>, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop,
+                              0, s->cell, s->mass_i, s->cellf, nullptr, s->local_cells);
+    }
     return launch_check(s, "clear_grid");
 }
 
@@ -251,7 +264,11 @@ int stage_update_grid(flowmpm_sim *s)
     if (rc) return rc;
     unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
     hipExtLaunchKernelGGL(mpm::update_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
-                          s->cell, s->mass_i, s->cellf, s->local_cells, s->params);
+                          s->cell, s->mass_i, s->mass_of_cellf, s->cellf, s->local_cells, s->params);
+    if (s->mass_of_cellf != s->mass_i) {     // the float grid now follows this step's mass words
+        s->mass_spare = s->mass_of_cellf;
+        s->mass_of_cellf = s->mass_i;
+    }
     return launch_check(s, "update_grid");
 }
 
@@ -470,6 +487,9 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->mass_i), (size_t)s->local_cells * sizeof(int)));
         HIP_TRY(s, hipMemsetAsync(s->cell, 0, (size_t)s->local_cells * sizeof(int4), s->stream));
         HIP_TRY(s, hipMemsetAsync(s->mass_i, 0, (size_t)s->local_cells * sizeof(int), s->stream));
+        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->mass_spare), (size_t)s->local_cells * sizeof(int)));
+        HIP_TRY(s, hipMemsetAsync(s->mass_spare, 0, (size_t)s->local_cells * sizeof(int), s->stream));
+        s->mass_of_cellf = s->mass_i;
         HIP_TRY(s, hipMemsetAsync(s->cellf, 0, (size_t)s->local_cells * sizeof(float4), s->stream));
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->d_modes), sizeof(mpm::ModeParams)));
         HIP_TRY(s, hipMemsetAsync(s->d_modes, 0, sizeof(mpm::ModeParams), s->stream));
@@ -510,6 +530,7 @@ int flowmpm_destroy(flowmpm_sim *s)
     if (s->store.base[1]) (void)hipFree(s->store.base[1]);
     if (s->cell) (void)hipFree(s->cell);
     if (s->mass_i) (void)hipFree(s->mass_i);
+    if (s->mass_spare) (void)hipFree(s->mass_spare);
     if (s->cellf) (void)hipFree(s->cellf);
     if (s->d_modes) (void)hipFree(s->d_modes);
     if (s->migration.counters) (void)hipFree(s->migration.counters);
@@ -571,10 +592,11 @@ int flowmpm_run_kernel(flowmpm_sim *s, int32_t kernel_id)
 {
     CHECK_SIM(s);
     // clearGrid opens a step: the profiling stride counts steps here as it does in flowmpm_step
-    if (kernel_id == FLOWMPM_KERNEL_CLEAR_GRID)
+    if (kernel_id == FLOWMPM_KERNEL_CLEAR_GRID || kernel_id == FLOWMPM_KERNEL_CLEAR_FIXED_GRID)
         s->profiling = s->profile_stride > 0 && (s->profile_step++ % s->profile_stride) == 0;
     switch (kernel_id) {
     case FLOWMPM_KERNEL_CLEAR_GRID: return stage_clear_grid(s);
+    case FLOWMPM_KERNEL_CLEAR_FIXED_GRID: return stage_clear_grid(s, false);
     case FLOWMPM_KERNEL_P2G1: return stage_p2g1(s);
     case FLOWMPM_KERNEL_P2G2: return stage_p2g2(s);
     case FLOWMPM_KERNEL_UPDATE_GRID: return stage_update_grid(s);
@@ -594,7 +616,7 @@ int flowmpm_step(flowmpm_sim *s, int32_t n_steps, double dtime)
     for (int k = 0; k < n_steps && rc == FLOWMPM_OK; k++) {
         s->params.time = (float)((double)time0 + (double)k * dtime);
         s->profiling = s->profile_stride > 0 && (s->profile_step++ % s->profile_stride) == 0;
-        if ((rc = stage_clear_grid(s))) break;
+        if ((rc = stage_clear_grid(s, false))) break;
         if (s->cfg.algorithm == FLOWMPM_ALGO_TILED) {
             if ((rc = stage_p2g_pass(s, false))) break;
             if ((rc = stage_p2g_pass(s, true))) break;

@@ -201,6 +201,8 @@ class SlabSimulation:
         fused = backend is None and algorithm == _lib.ALGO_TILED
         self.p2g_kernels = ((_lib.KERNEL_P2G_MASS, _lib.KERNEL_P2G_MOMENTUM) if fused
                             else (_lib.KERNEL_P2G1, _lib.KERNEL_P2G2))
+        # the device library's updateGrid keeps the float grid, so only the fixed-point grid is cleared
+        self.clear_kernel = _lib.KERNEL_CLEAR_FIXED_GRID if backend is None else _lib.KERNEL_CLEAR_GRID
         self.low = rank - 1 if rank > 0 else None
         self.high = rank + 1 if rank < world - 1 else None
         b = self.backend
@@ -327,7 +329,7 @@ class SlabSimulation:
     def step(self):
         b = self.backend
         p2g = self.p2g_kernels
-        b.run_kernel(_lib.KERNEL_CLEAR_GRID)      # touches no particle: runs while the counts travel
+        b.run_kernel(self.clear_kernel)           # touches no particle: runs while the counts travel
         self._finish_migration()
         b.run_kernel(p2g[0])
         self._exchange_planes(_lib.COMP_MASS)

@@ -48,6 +48,12 @@ extern "C" {
  * grid equals the reference's grid after p2g2 bit for bit.  flowmpm_step uses this form. */
 #define FLOWMPM_KERNEL_P2G_MASS     16
 #define FLOWMPM_KERNEL_P2G_MOMENTUM 17
+/* clearGrid of the fixed-point grid only (20 instead of 36 bytes per cell).  The float grid is
+ * then kept by the next FLOWMPM_KERNEL_UPDATE_GRID, which also writes the cleared value into
+ * the cells that held mass at the previous updateGrid and hold none now; after it the float
+ * grid equals the reference's bit for bit.  Timed as FLOWMPM_KERNEL_CLEAR_GRID.  flowmpm_step
+ * uses this form. */
+#define FLOWMPM_KERNEL_CLEAR_FIXED_GRID 18
 
 /* Timing slots reported by flowmpm_get_timings: the five kernels, then the
  * particle re-binning pass of the tiled algorithm (no reference counterpart). */
@@ -233,7 +239,7 @@ int flowmpm_grid_sums(flowmpm_sim *sim, int64_t sums[4]);
  * off, 1 times every launch, k > 1 times the launches of every k-th step of flowmpm_step
  * (a timed dispatch costs the queue a few microseconds; sampling keeps a timed run within a
  * fraction of a percent of an untimed one).  For flowmpm_run_kernel a step begins at each
- * FLOWMPM_KERNEL_CLEAR_GRID: the launches from the k-th such call up to the next one are
+ * clearGrid (either form): the launches from the k-th such call up to the next one are
  * timed. */
 int flowmpm_set_profiling(flowmpm_sim *sim, int32_t every_nth_step);
 int flowmpm_get_timings(flowmpm_sim *sim, flowmpm_timings *out);

@@ -129,6 +129,39 @@ def test_default_scene_digest(algo):
 
 
 @pytest.mark.parametrize("algo", ALGOS)
+def test_clear_of_the_fixed_grid_alone(oracle_binding, algo):
+    """clearGrid without the float grid: updateGrid has to zero the float cells the fluid has
+    left, also when a step is cleared twice or the two clears alternate."""
+    grid, n = (32, 16, 16), 5000
+    rec = moving_particles(n, grid, seed=23, vel=2.0)
+    h = _handle(grid, rec, algo)
+    orc = oracle_binding.Oracle(grid)
+    want = rec.copy()
+    u = oracle_binding.make_uniforms(grid, n, **DEFAULT_UNIFORMS)
+    p2g = ((_lib.KERNEL_P2G_MASS, _lib.KERNEL_P2G_MOMENTUM) if algo == _lib.ALGO_TILED
+           else (_lib.KERNEL_P2G1, _lib.KERNEL_P2G2))
+    emptied, occupied_before = 0, None
+    for k in range(12):
+        h.run_kernel(_lib.KERNEL_CLEAR_GRID if k == 5 else _lib.KERNEL_CLEAR_FIXED_GRID)
+        if k in (3, 6):
+            h.run_kernel(_lib.KERNEL_CLEAR_FIXED_GRID)
+        for kern in p2g + (_lib.KERNEL_UPDATE_GRID,):
+            h.run_kernel(kern)
+        if k == 8:
+            h.run_kernel(_lib.KERNEL_UPDATE_GRID)
+        h.run_kernel(_lib.KERNEL_G2P)
+        orc.run(want, u, 1, 0.0)
+        assert_bits_equal(h.download_grid_f32(), orc.cellf, "float grid at step %d" % k)
+        occupied = orc.cellf.reshape(-1, 4)[:, 3] != 0
+        if occupied_before is not None:
+            emptied += int((occupied_before & ~occupied).sum())
+        occupied_before = occupied
+    assert emptied > 0, "the case must contain cells that empty out"
+    assert_bits_equal(h.download_particles(), want, "particles after 12 steps")
+    h.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("rebin_interval", [1, 3, 50])
 def test_many_steps_match_oracle(oracle_binding, algo, rebin_interval):
     """20 steps: stale bins (rebin_interval > 1) must not change a single bit."""
