@@ -67,8 +67,9 @@ constexpr int kTiledThreads = 256;
 // small follow-up kernel sends their contributions straight to the global grid.  Keeping
 // that rare path out of the hot kernels keeps their register allocation small.
 struct Stragglers {
-    int *count;     // device scalar, zeroed before every tiled launch
-    int *list;      // slot indices, capacity = store capacity
+    int *count;       // device scalar: zero when a stage starts
+    int *next_count;  // the counter of the next stage, zeroed by this stage's follow-up kernel
+    int *list;        // slot indices, capacity = store capacity
 };
 
 // Re-binning control words, on the device.  The decision to re-bin is taken there, from the
@@ -96,7 +97,9 @@ struct TiledState {
     int *tile_start = nullptr;   // [n_tiles + 1]
     int4 *items = nullptr;       // work items {tile, begin, end, 0}
     int *n_items = nullptr;      // device scalar
-    Stragglers stragglers{nullptr, nullptr};
+    int *straggler_counts = nullptr;   // two device scalars used by alternate stages
+    int *straggler_list = nullptr;
+    int stage_parity = 0;        // which of the two the next stage counts into
 };
 
 // Two floats that one packed instruction (v_pk_mul_f32, v_pk_add_f32) operates on.
@@ -872,6 +875,7 @@ straggler_p2g_kernel(TiledWork w, FixedGrid g, Params P)
     const Store st = w.store.pick();
     int count, tail_begin;
     const int total = straggler_total(w, &count, &tail_begin);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *w.sg.next_count = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int j = i < count ? w.sg.list[i] : tail_begin + (i - count);
         float in[15];
@@ -896,6 +900,7 @@ straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
     int count, tail_begin;
     const int total = straggler_total(w, &count, &tail_begin);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *w.sg.next_count = 0;
         // bookkeeping of the step that ends here: every particle on this path counts as outside
         if (total) atomicAdd(&w.ctl->cum_drift, total);
         w.ctl->age += 1;
@@ -955,8 +960,10 @@ inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStr
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.items), (size_t)T.item_cap * sizeof(int4)), "hipMalloc items")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.n_items), sizeof(int)), "hipMalloc n_items")) return 1;
     if (chk(e = hipMemsetAsync(T.n_items, 0, sizeof(int), stream), "memset n_items")) return 1;
-    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.stragglers.count), 256), "hipMalloc straggler count")) return 1;
-    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.stragglers.list), (size_t)capacity * sizeof(int)), "hipMalloc straggler list")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.straggler_counts), 256), "hipMalloc straggler counts")) return 1;
+    if (chk(e = hipMemsetAsync(T.straggler_counts, 0, 256, stream), "memset straggler counts")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.straggler_list), (size_t)capacity * sizeof(int)), "hipMalloc straggler list")) return 1;
+    T.stage_parity = 0;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.ctl), sizeof(RebinCtl)), "hipMalloc rebin control")) return 1;
     if (chk(e = hipMemsetAsync(T.ctl, 0, sizeof(RebinCtl), stream), "memset rebin control")) return 1;
     T.valid = false;
@@ -972,8 +979,8 @@ inline void tiled_free(TiledState &T)
     if (T.tile_start) (void)hipFree(T.tile_start);
     if (T.items) (void)hipFree(T.items);
     if (T.n_items) (void)hipFree(T.n_items);
-    if (T.stragglers.count) (void)hipFree(T.stragglers.count);
-    if (T.stragglers.list) (void)hipFree(T.stragglers.list);
+    if (T.straggler_counts) (void)hipFree(T.straggler_counts);
+    if (T.straggler_list) (void)hipFree(T.straggler_list);
     if (T.ctl) (void)hipFree(T.ctl);
     T = TiledState{};
 }
@@ -1002,9 +1009,15 @@ inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P
     return 0;
 }
 
-inline TiledWork tiled_work(const TiledState &T, StoreSel ss, long long n)
+// The work description of the next stage.  Stages alternate between two straggler counters:
+// the follow-up kernel of a stage zeroes the one the next stage will count into, which saves a
+// memset launch per stage.
+inline TiledWork tiled_work(TiledState &T, StoreSel ss, long long n)
 {
-    return TiledWork{ss, T.items, T.n_items, T.ctl, (int)n, tile_dims(T), T.stragglers};
+    const Stragglers sg{T.straggler_counts + T.stage_parity, T.straggler_counts + (T.stage_parity ^ 1),
+                        T.straggler_list};
+    T.stage_parity ^= 1;
+    return TiledWork{ss, T.items, T.n_items, T.ctl, (int)n, tile_dims(T), sg};
 }
 
 // Upper bound of the work items any binning of n particles can produce.
@@ -1014,13 +1027,12 @@ inline unsigned item_bound(const TiledState &T, long long n)
     return (unsigned)std::max<long long>(b, 1);
 }
 
-// Every tiled stage is: zero the straggler counter, the tiled kernel, the straggler kernel.
+// Every tiled stage is: the tiled kernel, then the straggler kernel for what it left.
 // ev_start / ev_stop (may be null) receive the start and end timestamps of the tiled kernel.
 constexpr int kStragglerBlocks = 1024;
 
 #define FLOWMPM_TILED_STAGE(kernel, straggler_kernel, grid_ptr)                                              \
     do {                                                                                                    \
-        if (hipMemsetAsync(T.stragglers.count, 0, sizeof(int), stream) != hipSuccess) return 1;             \
         const TiledWork w = tiled_work(T, st, n);                                                           \
         hipExtLaunchKernelGGL(kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, ev_start,     \
                               ev_stop, 0, w, grid_ptr, P);                                                  \
@@ -1056,7 +1068,6 @@ inline int launch_p2g_momentum_tiled(TiledState &T, StoreSel st, long long n, Fi
 inline int launch_g2p_tiled(TiledState &T, StoreSel st, long long n, const float4 *cellf, const Params &P,
                             const ModeParams *modes, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    if (hipMemsetAsync(T.stragglers.count, 0, sizeof(int), stream) != hipSuccess) return 1;
     const dim3 grid(item_bound(T, n)), block(kTiledThreads);
     const TiledWork w = tiled_work(T, st, n);
     if (modes) {

@@ -128,6 +128,35 @@ def test_default_scene_digest(algo):
     h.close()
 
 
+@pytest.mark.parametrize("case", ["fast", "crowded"])
+def test_long_run_on_one_binning(oracle_binding, monkeypatch, case):
+    """No re-bin after the first one (the drift rule is off and the interval is never reached):
+    particles that leave their tile's arena are adopted by the tile they move into, or -- when
+    its list is full or it has no work item -- go to the global grids.  Every route must give
+    the reference's bits, for as long as the run lasts."""
+    monkeypatch.setenv("FLOWMPM_DRIFT_DIVISOR", "0")
+    if case == "fast":
+        grid, n, steps = (40, 24, 16), 6000, 60
+        rec = moving_particles(n, grid, seed=77, vel=3.0)
+    else:
+        # a block of fluid that fills a few tiles and spreads into empty ones: hundreds of
+        # particles enter tiles that have no work item, and adoption lists overflow
+        grid, n, steps = (32, 32, 32), 20000, 40
+        rec = moving_particles(n, grid, seed=78, vel=2.5)
+        rec[:, 0:3] = 10.0 + (rec[:, 0:3] - 2.0) * (9.0 / 28.0)
+    h = _handle(grid, rec, _lib.ALGO_TILED, rebin_interval=100000)
+    orc = oracle_binding.Oracle(grid, threads=8)
+    want = rec.copy()
+    u = oracle_binding.make_uniforms(grid, n, **DEFAULT_UNIFORMS)
+    for chunk in range(steps // 10):
+        h.step(10, 0.0)
+        orc.run(want, u, 10, 0.0)
+        assert np.array_equal(h.download_grid_i32(), orc.cell), "fixed-point grid after %d steps" % (10 * chunk + 10)
+        assert_bits_equal(h.download_particles(), want, "particles after %d steps" % (10 * chunk + 10))
+    assert h.timings()["rebin"]["performed"] == 1
+    h.close()
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 def test_clear_of_the_fixed_grid_alone(oracle_binding, algo):
     """clearGrid without the float grid: updateGrid has to zero the float cells the fluid has
