@@ -228,10 +228,14 @@ bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict
     if (!rebin_due(ctl, n, interval, force, divisor)) return;
     const Store st = ss.pick();
     const int lane = threadIdx.x & 63;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long j0 = (long long)blockIdx.x * blockDim.x; j0 < n; j0 += stride) {
+    // Each workgroup takes one contiguous run of particles: the store is nearly sorted, so a run
+    // touches two or three tile counters and few other workgroups touch the same ones (with a
+    // grid-stride loop every counter would be contended by dozens of workgroups at a time).
+    const long long per = (((long long)n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const long long run_begin = (long long)blockIdx.x * per, run_end = min((long long)n, run_begin + per);
+    for (long long j0 = run_begin; j0 < run_end; j0 += blockDim.x) {
         const long long j = j0 + threadIdx.x;
-        const bool valid = j < n;
+        const bool valid = j < run_end;
         int k = -1 - lane;   // distinct for idle lanes, never equal to a tile id
         if (valid) k = tile_of(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j], P, td);
         int prev = __shfl_up(k, 1);
