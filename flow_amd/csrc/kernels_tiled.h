@@ -53,10 +53,11 @@ constexpr int kTiledThreads = 256;
 #ifndef FLOWMPM_SLAB_FENCE
 #define FLOWMPM_SLAB_FENCE 1
 #endif
-// Software prefetch of the next particle's fields: neutral to slightly positive in g2p,
-// negative in the momentum pass (15 more VGPRs cost a wave per SIMD).
+// Software prefetch of the next particle's fields: neutral to slightly negative in g2p since its
+// sums became packed (0.633 vs 0.625 ms), negative in the momentum pass (15 more VGPRs cost a
+// wave per SIMD).
 #ifndef FLOWMPM_PREFETCH_G2P
-#define FLOWMPM_PREFETCH_G2P 1
+#define FLOWMPM_PREFETCH_G2P 0
 #endif
 #ifndef FLOWMPM_PREFETCH_P2G
 #define FLOWMPM_PREFETCH_P2G 0
@@ -795,7 +796,10 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
 
     // Software pipeline: the next particle's loads are issued before this particle's 18 stores
     // (the memory counter retires in order, so a load issued after them would wait for them).
-    G2PIn in, nx;
+    G2PIn in;
+#if FLOWMPM_PREFETCH_G2P
+    G2PIn nx;
+#endif
     int j = item.y + threadIdx.x;
     auto load = [&](G2PIn &r, int q) {
         r.px = st.slot(kPosX)[q]; r.py = st.slot(kPosY)[q]; r.pz = st.slot(kPosZ)[q];

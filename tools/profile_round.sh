@@ -1,12 +1,13 @@
 set -e
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r01d
+TAG=${1:-r01e}
+mkdir -p gpurun_out/$TAG
 export TMPDIR=/tmp
-timeout -k 10 300 python bench.py > gpurun_out/r01d/bench_16M_256cube.json 2> gpurun_out/r01d/bench.err
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01d/stats -- python3 bench.py --no-cpu-baseline > gpurun_out/r01d/bench_under_rocprof.json 2> gpurun_out/r01d/rocprof.err
-bash tools/pmc.sh r01d_fetch TCC_EA0_RDREQ_32B_sum FETCH_SIZE
-bash tools/pmc.sh r01d_write WRITE_SIZE TCC_EA0_WRREQ_64B_sum
-bash tools/pmc.sh r01d_sq SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-for t in fetch write sq; do python tools/pmc_summary.py gpurun_out/pmc_r01d_$t > gpurun_out/r01d/pmc_$t.txt; done
-cp $(find gpurun_out/r01d/stats -name "*kernel_stats.csv" | head -1) gpurun_out/r01d/kernel_stats_16M_256cube.csv
+timeout -k 10 300 python bench.py > gpurun_out/$TAG/bench_16M_256cube.json 2> gpurun_out/$TAG/bench.err
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/stats -- python3 bench.py --no-cpu-baseline > gpurun_out/$TAG/bench_under_rocprof.json 2> gpurun_out/$TAG/rocprof.err
+bash tools/pmc.sh ${TAG}_fetch TCC_EA0_RDREQ_32B_sum FETCH_SIZE
+bash tools/pmc.sh ${TAG}_write WRITE_SIZE TCC_EA0_WRREQ_64B_sum
+bash tools/pmc.sh ${TAG}_sq SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+for t in fetch write sq; do python tools/pmc_summary.py gpurun_out/pmc_${TAG}_$t > gpurun_out/$TAG/pmc_$t.txt; done
+cp $(find gpurun_out/$TAG/stats -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/kernel_stats_16M_256cube.csv
 echo done
