@@ -323,15 +323,25 @@ def run_distributed(args):
     resident = torch.tensor([sim.resident()], dtype=torch.int64, device=comm_dev)
     gathered = [torch.zeros_like(resident) for _ in range(world)]
     dist.all_gather(gathered, resident)
+    # load balance: every rank's own kernel time per step (sum of the sampled per-launch averages)
+    timings = handle.timings() if handle is not None else None
+    busy = 0.0
+    if timings is not None:
+        busy = sum(t["ms"] / t["launches"] for name, t in timings.items()
+                   if name in BYTES and t["launches"])
+    busy_t = torch.tensor([busy], dtype=torch.float64, device=comm_dev)
+    busy_all = [torch.zeros_like(busy_t) for _ in range(world)]
+    dist.all_gather(busy_all, busy_t)
     line = None
     if rank == 0:
         per_rank = [int(g.item()) for g in gathered]
+        per_rank_busy = [round(float(b.item()), 4) for b in busy_all]
         # rank 0's own launches (HIP events on its stream, sampled like the single-GPU run),
         # against the algorithmic bytes of the particles and cells that rank holds
         roof, per_kernel = None, None
         if handle is not None:
             local_cells = (starts[1] - starts[0]) * grid[1] * grid[2]
-            roof, per_kernel = roofline_of(handle.timings(), (n_start + per_rank[0]) // 2, local_cells)
+            roof, per_kernel = roofline_of(timings, (n_start + per_rank[0]) // 2, local_cells)
             roof["scope"] = "rank 0: %d planes, about %d particles" % (starts[1] - starts[0], (n_start + per_rank[0]) // 2)
         line = {
             "metric": "particle-substeps/sec", "value": n_total * args.steps / elapsed,
@@ -344,7 +354,10 @@ def run_distributed(args):
                        "scene": args.scene, "particles": n_total, "grid": list(grid), "algorithm": args.algorithm,
                        "noise": args.noise, "timing_stride": args.timing_stride,
                        "rebin_interval": args.rebin_interval, "parallelism": "slab%d" % world,
-                       "plane_starts": [int(s) for s in starts], "resident_per_rank_end": per_rank},
+                       "plane_starts": [int(s) for s in starts], "resident_per_rank_end": per_rank,
+                       "kernel_ms_per_step_per_rank": per_rank_busy,
+                       "kernel_time_imbalance_max_over_mean":
+                           round(max(per_rank_busy) / (sum(per_rank_busy) / world), 4) if sum(per_rank_busy) else None},
             "roofline": roof, "kernels": per_kernel, "cpu_baseline": None,
         }
     dist.destroy_process_group()
