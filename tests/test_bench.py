@@ -1,0 +1,116 @@
+"""bench.py: the pieces that need no GPU (roofline bookkeeping, defaults), and on the GPU the
+JSON line itself -- the keys the driver reads, and that the numbers in it agree with each other."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+             "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+
+
+def _timings(**ms):
+    return {name: {"ms": ms.get(name, 0.0) * 4, "launches": 4 if name in ms else 0} for name in bench.BYTES}
+
+
+def test_defaults_finish_in_minutes_on_one_gpu(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse_args()
+    assert (a.gpus, a.steps, a.warmup) == (1, 100, 20)
+    assert a.particles_log2 == 24 and a.grid == "" and a.scene == "ellipsoid" and a.mode == "chaos"
+
+
+def test_roofline_names_the_longest_launch_and_pairs_the_p2g_passes():
+    n, cells = 1 << 24, 256 ** 3
+    roof, per = bench.roofline_of(_timings(clearGrid=0.05, p2g1=0.14, p2g2=0.59, updateGrid=0.07, g2p=0.63), n, cells)
+    assert roof["kernel"] == "g2p" and roof["bound"] == "hbm" and roof["unit"] == "GB/s"
+    want = (96 * n + 16 * cells) / 0.63e-3 / 1e9
+    assert abs(roof["achieved"] - want) < 0.1 and abs(roof["frac"] - want / 8000.0) < 1e-4
+    assert abs(per["p2g"]["avg_ms"] - 0.73) < 1e-9
+    # when one of the two p2g passes is the longest launch the pair is judged: 116 N + 32 G bytes
+    roof, per = bench.roofline_of(_timings(clearGrid=0.05, p2g1=0.14, p2g2=0.70, updateGrid=0.07, g2p=0.63), n, cells)
+    assert roof["kernel"] == "p2g"
+    want = (116 * n + 32 * cells) / 0.84e-3 / 1e9
+    assert abs(roof["achieved"] - want) < 0.1
+    assert set(ROOFLINE_KEYS) <= set(roof)
+
+
+def test_algorithmic_bytes_per_step_add_up():
+    per_particle = sum(b[0] for b in bench.BYTES.values())
+    per_cell = sum(b[1] for b in bench.BYTES.values())
+    assert (per_particle, per_cell) == (212, 112)
+
+
+def test_measured_traffic_comes_from_the_committed_counter_passes():
+    key = "ellipsoid_%d_256x256x256" % (1 << 24)
+    for kernel in ("p2g", "g2p", "clearGrid", "updateGrid"):
+        assert bench.measured_traffic(kernel, key) > 0
+    assert bench.measured_traffic("g2p", "some other workload") is None
+
+
+def test_scene_uniforms_fix_the_rest_density_to_the_fill():
+    u = bench.scene_uniforms(1 << 20, 128 ** 3, "ellipsoid")
+    assert u["dt"] == 0.1 and u["noise"] == 0.0
+    assert abs(u["rest_density"] - (1 << 20) / (0.268 * 128 ** 3)) < 1e-9
+    assert bench.scene_uniforms(1 << 20, 128 ** 3, "ellipsoid", noise=1.0)["noise"] == 1.0
+
+
+def _last_json_line(text):
+    lines = [l for l in text.strip().splitlines() if l.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.gpu
+def test_the_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2",
+                        "--particles-log2", "18", "--grid", "64,64,64", "--cpu-steps", "1", "--timing-stride", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json_line(r.stdout)
+    assert set(LINE_KEYS) <= set(d)
+    assert d["metric"] == "particle-substeps/sec" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    n = d["config"]["particles"]
+    assert n == 1 << 18
+    assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    roof = d["roofline"]
+    assert set(ROOFLINE_KEYS) <= set(roof) and roof["bound"] == "hbm" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["avg_launch_ms"] > 0 and roof["kernel"] in ("p2g", "g2p", "clearGrid", "updateGrid")
+    cpu = d["cpu_baseline"]
+    assert set(CPU_KEYS) <= set(cpu) and cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
+    assert d["value"] > cpu["value"]
+
+
+@pytest.mark.gpu
+def test_the_two_rank_line_over_gloo():
+    """Two ranks on the one GPU, gloo transport: everything bench.py does for N > 1 except RCCL."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--dist-backend", "gloo", "--particles-log2", "18", "--slab-yz", "64",
+           "--slab-x-per-gpu", "32", "--steps", "6", "--warmup", "2", "--timing-stride", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = _last_json_line(r.stdout)
+    assert set(LINE_KEYS) <= set(d)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["particles"] == 2 << 18 and d["config"]["grid"] == [64, 64, 64]
+    assert sum(d["config"]["resident_per_rank_end"]) == 2 << 18
+    assert abs(d["value"] - (2 << 18) / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert set(ROOFLINE_KEYS) <= set(d["roofline"])
+    assert len(d["config"]["kernel_ms_per_step_per_rank"]) == 2
+    assert d["config"]["kernel_time_imbalance_max_over_mean"] >= 1.0
