@@ -40,6 +40,7 @@ EXPORTS = (
     "flowmpm_plane_add_i32", "flowmpm_plane_copy_out", "flowmpm_extract_leavers",
     "flowmpm_insert_arrivals", "flowmpm_set_mode_uniforms", "flowmpm_halo_words", "flowmpm_halo_pack",
     "flowmpm_halo_add", "flowmpm_find_leavers", "flowmpm_pack_leavers", "flowmpm_grid_sums",
+    "flowmpm_set_domain_particles",
 )
 
 
@@ -138,6 +139,7 @@ def load():
         "flowmpm_upload_particles": ([vp, fp, ip, i64], ctypes.c_int),
         "flowmpm_set_num_particles": ([vp, i64], ctypes.c_int),
         "flowmpm_get_num_particles": ([vp, i64p, i64p], ctypes.c_int),
+        "flowmpm_set_domain_particles": ([vp, i64], ctypes.c_int),
         "flowmpm_set_uniforms": ([vp, ctypes.POINTER(Uniforms)], ctypes.c_int),
         "flowmpm_step": ([vp, i32, ctypes.c_double], ctypes.c_int),
         "flowmpm_run_kernel": ([vp, i32], ctypes.c_int),

@@ -46,6 +46,7 @@ struct flowmpm_sim {
     long long capacity = 0;      // slots in the store
     long long resident = 0;      // particles on the device
     long long live = 0;          // simulated particles (== resident except set_num_particles)
+    long long domain_particles = 0;   // slab handles: uniforms.numParticles of the whole domain
     long long uploaded = 0;      // records given to upload (single GPU)
     mpm::StoreSel store{};       // tiled: two stores, re-binning gathers from one into the other
     int drift_divisor = 256;      // re-bin when (particles outside their arena) * divisor > particles
@@ -305,7 +306,8 @@ int stage_g2p(flowmpm_sim *s)
             value.grid_mode = s->uniforms.grid_mode;
             value.front_gravity_mode = s->uniforms.front_gravity_mode;
             value.hide_percentage = s->uniforms.hide_percentage;
-            value.num_particles = (unsigned)s->live;      // uniforms.numParticles (SIM:2513-2522)
+            // uniforms.numParticles (SIM:2513-2522): of the whole domain
+            value.num_particles = (unsigned)(s->slab ? s->domain_particles : s->live);
             s->modes_for_live = s->live;
             hipLaunchKernelGGL(store_modes_kernel, dim3(1), dim3(256), 0, s->stream, value, s->d_modes);
             if ((rc = launch_check(s, "store_modes"))) return rc;
@@ -352,9 +354,9 @@ int stage_rebin_if_needed(flowmpm_sim *s)
 
 int validate_uniforms(flowmpm_sim *s, const flowmpm_uniforms *u)
 {
-    if (u->hide_percentage > 0.0f && s->slab)
+    if (u->hide_percentage > 0.0f && s->slab && s->domain_particles <= 0)
         return fail(s, FLOWMPM_ERR_UNSUPPORTED,
-                    "hidePercentage > 0 on a slab handle (it needs the particle count of the whole domain)");
+                    "hidePercentage > 0 on a slab handle needs flowmpm_set_domain_particles first");
     if (u->cursor_interaction > 1u)
         return fail(s, FLOWMPM_ERR_INVALID, "cursorInteraction must be 0 or 1");
     return FLOWMPM_OK;
@@ -554,6 +556,16 @@ int flowmpm_upload_particles(flowmpm_sim *s, const float *aos, const int32_t *id
     s->resident = s->live = s->uploaded = count;
     s->shadow.clear();
     s->tiled.valid = false;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_set_domain_particles(flowmpm_sim *s, int64_t count)
+{
+    CHECK_SIM(s);
+    if (!s->slab) return fail(s, FLOWMPM_ERR_INVALID, "set_domain_particles is for slab handles");
+    if (count < 1 || count > 4294967295LL) return fail(s, FLOWMPM_ERR_INVALID, "domain particle count out of range");
+    s->domain_particles = count;
+    s->modes_stale = true;
     return FLOWMPM_OK;
 }
 

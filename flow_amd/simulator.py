@@ -77,6 +77,11 @@ class Handle:
     def set_num_particles(self, n):
         self._chk(self.L.flowmpm_set_num_particles(self._h, int(n)))
 
+    def set_domain_particles(self, n):
+        """Slab handles: uniforms.numParticles of the whole domain (the hide-percentage branch
+        divides the particle id by it)."""
+        self._chk(self.L.flowmpm_set_domain_particles(self._h, int(n)))
+
     def num_particles(self):
         live, resident = ctypes.c_int64(), ctypes.c_int64()
         self._chk(self.L.flowmpm_get_num_particles(self._h, ctypes.byref(live), ctypes.byref(resident)))

@@ -122,6 +122,9 @@ class GpuSlabBackend:
     def set_mode_uniforms(self, modes):
         self.handle.set_mode_uniforms(modes)
 
+    def set_domain_particles(self, n):
+        self.handle.set_domain_particles(n)
+
     def run_kernel(self, kernel_id):
         self.handle.run_kernel(kernel_id)
 
@@ -225,6 +228,15 @@ class SlabSimulation:
         rank that owns floor(x), then uploaded there with its global id."""
         records = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, _lib.PARTICLE_STRIDE)
         ids = np.ascontiguousarray(ids, dtype=np.int32)
+        # uniforms.numParticles of the whole domain (mlsMpmSimulator.js:2513-2522): g2p's
+        # hide-percentage branch divides the particle id by it
+        total = records.shape[0]
+        if self.world > 1:
+            t = torch.tensor([total], dtype=torch.int64, device=self._comm_device())
+            self.dist.all_reduce(t)
+            total = int(t.item())
+        if total > 0 and hasattr(self.backend, "set_domain_particles"):
+            self.backend.set_domain_particles(total)
         starts = np.asarray(self.plane_starts)
         dest = np.clip(np.searchsorted(starts, np.floor(records[:, 0]).astype(np.int64), side="right") - 1,
                        0, self.world - 1)

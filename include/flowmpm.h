@@ -128,7 +128,8 @@ typedef struct {
     float mouse_force[3];             /* SIM:258, 2533 */
     uint32_t cursor_interaction;      /* SIM:259 */
     float hide_percentage;            /* SIM:260, read at SIM:441-442; slab handles take 0 only
-                                       * (FLOWMPM_ERR_UNSUPPORTED otherwise) */
+                                       * (FLOWMPM_ERR_UNSUPPORTED otherwise) until
+                                       * flowmpm_set_domain_particles has been called */
     uint32_t grid_mode;               /* SIM:152, read at SIM:444 */
     uint32_t front_gravity_mode;      /* SIM:153, read at SIM:485, 1316, 1365 */
 } flowmpm_uniforms;
@@ -197,6 +198,10 @@ int flowmpm_upload_particles(flowmpm_sim *sim, const float *aos, const int32_t *
  * `count` particle ids only.  Single-GPU handles only. */
 int flowmpm_set_num_particles(flowmpm_sim *sim, int64_t count);
 int flowmpm_get_num_particles(flowmpm_sim *sim, int64_t *live, int64_t *resident);
+/* Slab handles only: uniforms.numParticles of the whole domain (SIM:151, 2513-2522), which the
+ * hide-percentage branch of g2p divides the particle id by (SIM:444-483).  A slab only knows its
+ * resident particles, so hidePercentage > 0 is accepted on a slab handle once this is set. */
+int flowmpm_set_domain_particles(flowmpm_sim *sim, int64_t count);
 
 /* The uniform writes of update() (SIM:2496-2534). */
 int flowmpm_set_uniforms(flowmpm_sim *sim, const flowmpm_uniforms *u);

@@ -107,7 +107,7 @@ def lib():
         L.orc_step.argtypes = [fp, ip, fp, up]
         mp = ctypes.POINTER(ModeUniforms)
         L.orc_g2p_modes.argtypes = [fp, fp, up, mp]
-        L.orc_g2p_modes_ids.argtypes = [fp, ip, fp, up, mp]
+        L.orc_g2p_modes_ids.argtypes = [fp, ip, ctypes.c_int64, fp, up, mp]
         L.orc_step_modes.argtypes = [fp, ip, fp, up, mp]
         L.orc_run.argtypes = [fp, ip, fp, up, ctypes.c_int, ctypes.c_double]
         L.orc_tri_noise3d.argtypes = [fp, ctypes.c_float, ctypes.c_float, fp]
@@ -184,14 +184,17 @@ class Oracle:
         self._t()
         self.L.orc_step(_fp(particles), _ip(self.cell), _fp(self.cellf), ctypes.byref(u))
 
-    def g2p_modes(self, particles, u, modes, ids=None):
-        """ids: the reference buffer index of each record (default: its position)."""
+    def g2p_modes(self, particles, u, modes, ids=None, count=None):
+        """ids: the reference buffer index of each record (default: its position); count: how
+        many records `particles` holds when it is a subset of the buffer (u.num_particles is then
+        the size of the whole buffer)."""
         self._t()
-        if ids is None:
+        if ids is None and count is None:
             self.L.orc_g2p_modes(_fp(particles), _fp(self.cellf), ctypes.byref(u), ctypes.byref(modes))
         else:
-            self.L.orc_g2p_modes_ids(_fp(particles), _ip(ids), _fp(self.cellf), ctypes.byref(u),
-                                     ctypes.byref(modes))
+            self.L.orc_g2p_modes_ids(_fp(particles), _ip(ids) if ids is not None else None,
+                                     ctypes.c_int64(-1 if count is None else int(count)), _fp(self.cellf),
+                                     ctypes.byref(u), ctypes.byref(modes))
 
     def step_modes(self, particles, u, modes):
         self._t()

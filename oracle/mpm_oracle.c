@@ -625,12 +625,12 @@ static void g2p_modes_one(float *P, int32_t index, const float *cellf, const orc
     }
 }
 
-void orc_g2p_modes_ids(float *particles, const int32_t *ids, const float *cellf, const orc_uniforms *u,
-                       const orc_mode_uniforms *m)
+void orc_g2p_modes_ids(float *particles, const int32_t *ids, int64_t count, const float *cellf,
+                       const orc_uniforms *u, const orc_mode_uniforms *m)
 {
     static const orc_mode_uniforms zero_modes;
     if (!m) m = &zero_modes;
-    int64_t n = u->num_particles;
+    int64_t n = count >= 0 ? count : (int64_t)u->num_particles;
 #pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int64_t i = 0; i < n; i++)
         g2p_modes_one(particles + i * ORC_STRIDE, ids ? ids[i] : (int32_t)i, cellf, u, m);
@@ -638,7 +638,7 @@ void orc_g2p_modes_ids(float *particles, const int32_t *ids, const float *cellf,
 
 void orc_g2p_modes(float *particles, const float *cellf, const orc_uniforms *u, const orc_mode_uniforms *m)
 {
-    orc_g2p_modes_ids(particles, NULL, cellf, u, m);
+    orc_g2p_modes_ids(particles, NULL, -1, cellf, u, m);
 }
 
 void orc_step_modes(float *particles, int32_t *cell, float *cellf, const orc_uniforms *u,

@@ -104,10 +104,12 @@ void orc_g2p(float *particles, const float *cellf, const orc_uniforms *u);
  * is uniforms.numParticles).  m == NULL means all mode uniforms are zero. */
 void orc_g2p_modes(float *particles, const float *cellf, const orc_uniforms *u,
                    const orc_mode_uniforms *m);
-/* The same over a subset of the reference's buffer: ids[i] is the instanceIndex of record i
- * (a slab of a decomposed run holds particles in arbitrary order).  ids == NULL: i itself. */
-void orc_g2p_modes_ids(float *particles, const int32_t *ids, const float *cellf, const orc_uniforms *u,
-                       const orc_mode_uniforms *m);
+/* The same over a subset of the reference's buffer: `count` records, ids[i] being the
+ * instanceIndex of record i (a slab of a decomposed run holds some of the particles, in arbitrary
+ * order), while u->num_particles stays uniforms.numParticles of the whole buffer.  ids == NULL:
+ * i itself; count < 0: u->num_particles records. */
+void orc_g2p_modes_ids(float *particles, const int32_t *ids, int64_t count, const float *cellf,
+                       const orc_uniforms *u, const orc_mode_uniforms *m);
 void orc_step_modes(float *particles, int32_t *cell, float *cellf, const orc_uniforms *u,
                     const orc_mode_uniforms *m);
 

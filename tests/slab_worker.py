@@ -35,12 +35,19 @@ class OracleSlabBackend:
         self.rec = np.zeros((0, 28), np.float32)
         self.ids = np.zeros(0, np.int32)
         self.uniform_kw = {}
+        self.domain_particles = 0
         self.modes = None
         self.plane_words = grid[1] * grid[2] * 4
         self.torch_device = torch.device("cpu")
 
-    def _u(self):
-        return self.binding.make_uniforms(self.grid, self.rec.shape[0], **self.uniform_kw)
+    def _u(self, whole_domain=False):
+        """The oracle loops over uniforms.numParticles records; only the mode branches of g2p,
+        which get their record count separately, see the particle count of the whole domain."""
+        n = self.domain_particles if (whole_domain and self.domain_particles) else self.rec.shape[0]
+        return self.binding.make_uniforms(self.grid, n, **self.uniform_kw)
+
+    def set_domain_particles(self, n):
+        self.domain_particles = int(n)
 
     def set_uniforms(self, **kw):
         self.uniform_kw = kw
@@ -61,7 +68,8 @@ class OracleSlabBackend:
             if self.modes is None:
                 self.orc.g2p(self.rec, self._u())
             else:
-                self.orc.g2p_modes(self.rec, self._u(), self.modes, ids=np.ascontiguousarray(self.ids))
+                self.orc.g2p_modes(self.rec, self._u(whole_domain=True), self.modes,
+                                   ids=np.ascontiguousarray(self.ids), count=self.rec.shape[0])
 
     def upload(self, records, ids):
         self.rec, self.ids = np.ascontiguousarray(records, np.float32).copy(), np.asarray(ids, np.int32).copy()

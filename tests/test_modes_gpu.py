@@ -143,9 +143,18 @@ def test_mode_errors(oracle_binding):
     h.close()
     slab = flow_amd.Handle((16, 16, 16), 16, slab=(4, 8))
     with pytest.raises(_lib.FlowMpmError) as e:
-        slab.set_uniforms(hide_percentage=10.0)
+        slab.set_uniforms(hide_percentage=10.0)        # the slab does not know the domain's particle count
     assert e.value.code == _lib.ERR_UNSUPPORTED
+    slab.set_domain_particles(1000)
+    slab.set_uniforms(hide_percentage=10.0)
     slab.close()
+    with pytest.raises(_lib.FlowMpmError) as e:
+        h2 = flow_amd.Handle((16, 16, 16), 16)
+        try:
+            h2.set_domain_particles(1000)                  # single-GPU handles count their own particles
+        finally:
+            h2.close()
+    assert e.value.code == _lib.ERR_INVALID
 
 
 def test_simulator_class_toggle_grid_mode(oracle_binding):

@@ -94,7 +94,7 @@ def _mode_reference_run(oracle_binding, case_name, n, steps, vel):
     return rec, orc
 
 
-@pytest.mark.parametrize("case_name", ["image_grid", "everything"])
+@pytest.mark.parametrize("case_name", ["image_grid", "everything", "hide_60_sphere_mouse"])
 def test_slab_protocol_with_mode_forces(oracle_binding, tmp_path, case_name):
     """The mode branches key on the particle's buffer index (grid mode) and colour, both of
     which must survive migration between slabs."""
@@ -215,7 +215,7 @@ def test_two_rank_rehearsal_on_one_gpu(oracle_binding, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case_name", ["image_grid", "everything"])
+@pytest.mark.parametrize("case_name", ["image_grid", "everything", "hide_60_sphere_mouse"])
 def test_two_rank_rehearsal_with_mode_forces(oracle_binding, tmp_path, case_name):
     n, steps, vel = 20000, 6, 4.0
     _launch(2, tmp_path, "--backend", "gpu", "--grid", "128,64,64", "--particles", str(n),
