@@ -100,37 +100,59 @@ __device__ __forceinline__ Stencil make_stencil(float px, float py, float pz)
     return s;
 }
 
-// src/common/noise.js:3-13
-__device__ __forceinline__ float tri(float x) { return fabsf(fract(x) - 0.5f); }
+// src/common/noise.js:3-13.  NONNEG: the caller guarantees x is +0 or a positive normal number;
+// v_fract_f32 then returns exactly x - floor(x) (checked over every such bit pattern by
+// tools/ubench/fract_check.hip; the instruction clamps below 1, which only differs for tiny
+// negative x) and saves the separate floor.
+template <bool NONNEG>
+__device__ __forceinline__ float tri_t(float x)
+{
+    return fabsf((NONNEG ? __builtin_amdgcn_fractf(x) : fract(x)) - 0.5f);
+}
+__device__ __forceinline__ float tri(float x) { return tri_t<false>(x); }
 
 // src/common/noise.js:49-80.  Parameter names follow the reference signature; the
 // g2p call site (SIM:1318) passes the clock as `speed` and 0.11 as `time`.
-__device__ __forceinline__ Vec3 tri_noise3d(Vec3 position, float speed, float time)
+template <bool NONNEG>
+__device__ __forceinline__ Vec3 tri_noise3d_t(Vec3 position, float s)
 {
     float px = position.x, py = position.y, pz = position.z;
     float bx = px, by = py, bz = pz;
     float z = 1.4f;
     float rx = 0.0f, ry = 0.0f, rz = 0.0f;
-    const float s = time * (0.1f * speed);
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         float b2x = bx * 2.0f, b2y = by * 2.0f, b2z = bz * 2.0f;
         // tri3 (noise.js:27-37)
-        float dgx = tri(b2z + tri(b2y * 1.0f));
-        float dgy = tri(b2z + tri(b2x * 1.0f));
-        float dgz = tri(b2y + tri(b2x * 1.0f));
+        float dgx = tri_t<NONNEG>(b2z + tri_t<NONNEG>(b2y * 1.0f));
+        float dgy = tri_t<NONNEG>(b2z + tri_t<NONNEG>(b2x * 1.0f));
+        float dgz = tri_t<NONNEG>(b2y + tri_t<NONNEG>(b2x * 1.0f));
         px = px + (dgx + s); py = py + (dgy + s); pz = pz + (dgz + s);
         bx = bx * 1.8f; by = by * 1.8f; bz = bz * 1.8f;
         z = z * 1.5f;
         px = px * 1.2f; py = py * 1.2f; pz = pz * 1.2f;
-        float i0 = tri(py), i1 = tri(pz), i2 = tri(px);
-        float m0 = tri(px + i0), m1 = tri(py + i1), m2 = tri(pz + i2);
-        float t0 = tri(pz + m0), t1 = tri(px + m1), t2 = tri(py + m2);
+        float i0 = tri_t<NONNEG>(py), i1 = tri_t<NONNEG>(pz), i2 = tri_t<NONNEG>(px);
+        float m0 = tri_t<NONNEG>(px + i0), m1 = tri_t<NONNEG>(py + i1), m2 = tri_t<NONNEG>(pz + i2);
+        float t0 = tri_t<NONNEG>(pz + m0), t1 = tri_t<NONNEG>(px + m1), t2 = tri_t<NONNEG>(py + m2);
         // z is a compile-time constant here (the loop is unrolled): 2.1, 3.15, 4.725, 7.0875
         rx = rx + div_by_const(t0, z); ry = ry + div_by_const(t1, z); rz = rz + div_by_const(t2, z);
         bx = bx + 0.14f; by = by + 0.14f; bz = bz + 0.14f;
     }
     return Vec3{rx, ry, rz};
+}
+
+__device__ __forceinline__ Vec3 tri_noise3d(Vec3 position, float speed, float time)
+{
+    const float s = time * (0.1f * speed);
+    // Every argument of tri() is a sum or product of the position components, s, constants and
+    // earlier tri() values (all >= 0), so when those four are +0 or positive normal numbers --
+    // any particle inside the grid, any non-negative clock -- so is every argument.
+    constexpr int kPosZeroOrNormal = (1 << 6) | (1 << 8);
+    const bool nonneg = __builtin_amdgcn_class(position.x, kPosZeroOrNormal) &&
+                        __builtin_amdgcn_class(position.y, kPosZeroOrNormal) &&
+                        __builtin_amdgcn_class(position.z, kPosZeroOrNormal) &&
+                        __builtin_amdgcn_class(s, kPosZeroOrNormal);
+    return nonneg ? tri_noise3d_t<true>(position, s) : tri_noise3d_t<false>(position, s);
 }
 
 __device__ __forceinline__ Vec3 normalize3(Vec3 v)

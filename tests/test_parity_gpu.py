@@ -284,6 +284,25 @@ def test_mouse_force_and_zero_noise(oracle_binding, algo):
     h.close()
 
 
+@pytest.mark.parametrize("algo", ALGOS)
+def test_noise_with_a_negative_clock(oracle_binding, algo):
+    """With positions and clock not negative every argument of the noise's tri() is +0 or a
+    positive normal number and the device uses v_fract_f32; a negative clock makes arguments
+    negative, where only x - floor(x) is the reference's fract (it rounds to 1.0 for tiny
+    negative x, the instruction clamps below 1), so the device must take its general path."""
+    grid, n = (32, 16, 16), 4000
+    rec = moving_particles(n, grid, seed=26)
+    for time in (-0.0, -2.75, -1.0e-30):
+        uni = dict(DEFAULT_UNIFORMS, noise=1.5, time=time)
+        h = _handle(grid, rec, algo, uniforms=uni)
+        orc = oracle_binding.Oracle(grid)
+        want = rec.copy()
+        h.step(3, 0.0)
+        orc.run(want, oracle_binding.make_uniforms(grid, n, **uni), 3, 0.0)
+        assert_bits_equal(h.download_particles(), want, "particles, time %r" % time)
+        h.close()
+
+
 def test_scatter_and_tiled_agree_at_full_size():
     """Benchmark configuration 2 (2^20 particles, 128^3): too big for the oracle in a test, so
     check what is size-independent: both algorithms produce identical bits, and the fixed-point
