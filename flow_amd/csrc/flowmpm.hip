@@ -56,7 +56,23 @@ struct flowmpm_sim {
     // whose updateGrid last wrote it.  Either mass_i or mass_spare.
     int *mass_of_cellf = nullptr;
     int *mass_spare = nullptr;
-    mpm::FixedGrid fixed() const { return mpm::FixedGrid{reinterpret_cast<int *>(cell), mass_i}; }
+    // Tiled handles: per-tile bits saying which buffer may be non-zero where (mpm::FixedGrid).
+    int *dirty = nullptr;
+    int *mass_first = nullptr;   // the mass buffer that owns bit 1 (the other one owns bit 2)
+    // p2g1 and the mass pass set the bits from the particles they scatter; p2g2 and the momentum
+    // pass scatter the same particles over the same cells and rely on that.  False whenever that
+    // is not known to hold (after a clear, a g2p, or any change of the particle set).
+    bool tiles_marked = false;
+    int mass_bit(const int *buffer) const { return buffer == mass_first ? 2 : 4; }
+    mpm::FixedGrid fixed() const
+    {
+        return mpm::FixedGrid{reinterpret_cast<int *>(cell), mass_i, dirty, 1 | mass_bit(mass_i)};
+    }
+    // a slab's boundary planes receive the neighbours' contributions too, which set no bits
+    mpm::TileRange tile_range() const
+    {
+        return slab ? mpm::TileRange{0, cfg.slab_nx / mpm::kTX} : mpm::TileRange{-1, 1 << 30};
+    }
     float4 *cellf = nullptr;
     long long local_cells = 0;
     std::vector<float> shadow;   // host copy of records beyond `live` (single GPU)
@@ -186,16 +202,33 @@ int stage_clear_grid(flowmpm_sim *s, bool float_grid = true)
         hipExtLaunchKernelGGL(mpm::clear_grid_kernel<true>, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
                               s->cell, s->mass_i, s->cellf, s->mass_spare, s->local_cells);
         s->mass_of_cellf = s->mass_i;       // all zero, like the float grid
+        if (s->dirty) HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
     } else {
         if (s->mass_i == s->mass_of_cellf) std::swap(s->mass_i, s->mass_spare);
-        hipExtLaunchKernelGGL(mpm::clear_grid_kernel<false>, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop,
-                              0, s->cell, s->mass_i, s->cellf, nullptr, s->local_cells);
+        if (s->dirty)
+            hipExtLaunchKernelGGL(mpm::clear_tiles_kernel, dim3(s->tiled.n_tiles), dim3(256), 0, s->stream, t.start,
+                                  t.stop, 0, s->cell, s->mass_i, s->dirty, s->mass_bit(s->mass_i),
+                                  mpm::tile_dims(s->tiled), s->params, s->tile_range());
+        else
+            hipExtLaunchKernelGGL(mpm::clear_grid_kernel<false>, dim3(blocks), dim3(256), 0, s->stream, t.start,
+                                  t.stop, 0, s->cell, s->mass_i, s->cellf, nullptr, s->local_cells);
     }
+    s->tiles_marked = false;
     return launch_check(s, "clear_grid");
 }
 
 int stage_rebin_if_needed(flowmpm_sim *s);
 inline bool is_tiled(const flowmpm_sim *s);
+
+// Before a p2g stage that sets no tile bits itself: if the stage that sets them has not run on
+// these particles since the last clear, every tile counts as dirty.
+int assume_all_tiles_dirty_unless_marked(flowmpm_sim *s)
+{
+    if (!s->dirty || s->tiles_marked) return FLOWMPM_OK;
+    HIP_TRY(s, hipMemsetAsync(s->dirty, 0x07, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
+    s->tiles_marked = true;
+    return FLOWMPM_OK;
+}
 
 int stage_p2g1(flowmpm_sim *s)
 {
@@ -213,6 +246,7 @@ int stage_p2g1(flowmpm_sim *s)
                                   t.start, t.stop, 0, s->store, s->live, s->fixed(), s->params);
         }
         if ((rc = launch_check(s, "p2g1"))) return rc;
+        s->tiles_marked = true;
     }
     return FLOWMPM_OK;
 }
@@ -222,6 +256,7 @@ int stage_p2g2(flowmpm_sim *s)
     int rc;
     if (is_tiled(s) && (rc = stage_rebin_if_needed(s))) return rc;
     if (s->live > 0) {
+        if ((rc = assume_all_tiles_dirty_unless_marked(s))) return rc;
         TimedLaunch t;
         if ((rc = timing_events(s, FLOWMPM_KERNEL_P2G2, &t))) return rc;
         if (is_tiled(s)) {
@@ -246,6 +281,7 @@ int stage_p2g_pass(flowmpm_sim *s, bool momentum)
     if (!is_tiled(s)) return fail(s, FLOWMPM_ERR_INVALID, "the mass/momentum passes belong to the tiled algorithm");
     if ((rc = stage_rebin_if_needed(s))) return rc;
     if (s->live > 0) {
+        if (momentum && (rc = assume_all_tiles_dirty_unless_marked(s))) return rc;
         TimedLaunch t;
         if ((rc = timing_events(s, momentum ? FLOWMPM_KERNEL_P2G2 : FLOWMPM_KERNEL_P2G1, &t))) return rc;
         rc = momentum ? mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream,
@@ -254,6 +290,7 @@ int stage_p2g_pass(flowmpm_sim *s, bool momentum)
                                                    t.start, t.stop);
         if (rc) return fail(s, FLOWMPM_ERR_HIP, "p2g pass: could not reset the straggler counter");
         if ((rc = launch_check(s, momentum ? "p2g_momentum" : "p2g_mass"))) return rc;
+        if (!momentum) s->tiles_marked = true;
     }
     return FLOWMPM_OK;
 }
@@ -264,8 +301,14 @@ int stage_update_grid(flowmpm_sim *s)
     int rc = timing_events(s, FLOWMPM_KERNEL_UPDATE_GRID, &t);
     if (rc) return rc;
     unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
-    hipExtLaunchKernelGGL(mpm::update_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
-                          s->cell, s->mass_i, s->mass_of_cellf, s->cellf, s->local_cells, s->params);
+    if (s->dirty)
+        hipExtLaunchKernelGGL(mpm::update_grid_tiles_kernel, dim3(s->tiled.n_tiles), dim3(256), 0, s->stream, t.start,
+                              t.stop, 0, s->cell, s->mass_i, s->mass_of_cellf, s->cellf, s->dirty,
+                              s->mass_bit(s->mass_i) | s->mass_bit(s->mass_of_cellf), mpm::tile_dims(s->tiled),
+                              s->params, s->tile_range());
+    else
+        hipExtLaunchKernelGGL(mpm::update_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
+                              s->cell, s->mass_i, s->mass_of_cellf, s->cellf, s->local_cells, s->params);
     if (s->mass_of_cellf != s->mass_i) {     // the float grid now follows this step's mass words
         s->mass_spare = s->mass_of_cellf;
         s->mass_of_cellf = s->mass_i;
@@ -323,6 +366,7 @@ int stage_g2p(flowmpm_sim *s)
                                             t.start, t.stop)))
                 return fail(s, FLOWMPM_ERR_HIP, "g2p_tiled launch failed");
             s->tiled.checked = false;      // the next step decides anew
+            s->tiles_marked = false;       // the particles move
         } else if (modes) {
             hipExtLaunchKernelGGL(mpm::g2p_gather_kernel<true>, dim3(blocks_for(s->live, 256)), dim3(256), 0,
                                   s->stream, t.start, t.stop, 0, s->store, s->live, s->cellf, s->params, modes);
@@ -492,6 +536,7 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->mass_spare), (size_t)s->local_cells * sizeof(int)));
         HIP_TRY(s, hipMemsetAsync(s->mass_spare, 0, (size_t)s->local_cells * sizeof(int), s->stream));
         s->mass_of_cellf = s->mass_i;
+        s->mass_first = s->mass_i;
         HIP_TRY(s, hipMemsetAsync(s->cellf, 0, (size_t)s->local_cells * sizeof(float4), s->stream));
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->d_modes), sizeof(mpm::ModeParams)));
         HIP_TRY(s, hipMemsetAsync(s->d_modes, 0, sizeof(mpm::ModeParams), s->stream));
@@ -504,6 +549,8 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
                 return fail(s, FLOWMPM_ERR_HIP, "tiled_init: " + msg);
             s->store.cur = &s->tiled.ctl->cur;
             if (const char *env = getenv("FLOWMPM_DRIFT_DIVISOR")) s->drift_divisor = atoi(env);
+            HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->dirty), (size_t)s->tiled.n_tiles * sizeof(int)));
+            HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
         }
         HIP_TRY(s, hipStreamSynchronize(s->stream));
         return FLOWMPM_OK;
@@ -533,6 +580,7 @@ int flowmpm_destroy(flowmpm_sim *s)
     if (s->cell) (void)hipFree(s->cell);
     if (s->mass_i) (void)hipFree(s->mass_i);
     if (s->mass_spare) (void)hipFree(s->mass_spare);
+    if (s->dirty) (void)hipFree(s->dirty);
     if (s->cellf) (void)hipFree(s->cellf);
     if (s->d_modes) (void)hipFree(s->d_modes);
     if (s->migration.counters) (void)hipFree(s->migration.counters);
@@ -556,6 +604,7 @@ int flowmpm_upload_particles(flowmpm_sim *s, const float *aos, const int32_t *id
     s->resident = s->live = s->uploaded = count;
     s->shadow.clear();
     s->tiled.valid = false;
+    s->tiles_marked = false;
     return FLOWMPM_OK;
 }
 
@@ -699,6 +748,7 @@ int flowmpm_set_num_particles(flowmpm_sim *s, int64_t count)
     s->resident = s->live = count;
     s->shadow.assign(all.begin() + (size_t)count * 28, all.end());
     s->tiled.valid = false;
+    s->tiles_marked = false;
     return FLOWMPM_OK;
 }
 
@@ -946,6 +996,7 @@ int flowmpm_extract_leavers(flowmpm_sim *s, const int32_t *plane_starts, int32_t
     if (rc == 2) return fail(s, FLOWMPM_ERR_CAPACITY, "extract_leavers: " + msg);
     if (rc) return fail(s, FLOWMPM_ERR_INVALID, "extract_leavers: " + msg);
     s->resident = s->live = new_resident;
+    s->tiles_marked = false;
     return FLOWMPM_OK;
 }
 
@@ -978,6 +1029,7 @@ int flowmpm_pack_leavers(flowmpm_sim *s, const int64_t *counts, int32_t n_ranks,
     if (rc == 2) return fail(s, FLOWMPM_ERR_CAPACITY, "pack_leavers: " + msg);
     if (rc) return fail(s, FLOWMPM_ERR_INVALID, "pack_leavers: " + msg);
     s->resident = s->live = new_resident;
+    s->tiles_marked = false;
     return FLOWMPM_OK;
 }
 
@@ -995,6 +1047,7 @@ int flowmpm_insert_arrivals(flowmpm_sim *s, const void *dev_in, int64_t count)
     if (rc) return rc;
     s->resident += count;
     s->live = s->resident;      // arrivals sit past the binned range until the next re-bin
+    s->tiles_marked = false;
     return FLOWMPM_OK;
 }
 

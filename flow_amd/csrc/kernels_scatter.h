@@ -57,6 +57,12 @@ struct StoreSel {
 struct FixedGrid {
     int *cell;      // 4 ints per cell; word 3 is not used on the device
     int *mass;      // 1 int per cell
+    // Tiled handles only (else null): one word per 8x8x8 tile of cells whose bits say which
+    // buffers may hold a non-zero word inside the tile -- bit 0 the momentum records, bits 1 and
+    // 2 the two mass buffers.  Every kernel that adds to the grid sets `dirty_bits` for the tiles
+    // it touches; clearGrid and updateGrid skip the tiles whose bits are clear.
+    int *dirty;
+    int dirty_bits;
 };
 
 // Local linear cell index (SIM:286-290) or -1 when the cell is outside the planes
@@ -186,6 +192,26 @@ p2g2_scatter_kernel(StoreSel ss, long long n, FixedGrid g, Params P)
 // non-zero only where `mass_of_cellf` -- the mass words of the step that last wrote it -- is
 // positive, so when clearGrid skipped the float grid the zeros are written here, and only into
 // the cells the fluid has left since.  mass_of_cellf may be mass_i itself (float grid cleared).
+__device__ __forceinline__ void update_grid_cell(const int4 *__restrict__ cell, const int *__restrict__ mass_i,
+                                                 const int *__restrict__ mass_of_cellf, float4 *__restrict__ cellf,
+                                                 long long i, int x, int y, int z, const Params &P)
+{
+    const int before = mass_of_cellf[i];
+    float mass = decode_fixed(mass_i[i]);
+    if (!(mass > 0.0f)) {
+        if (before > 0) cellf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    int4 c = cell[i];
+    float vx = decode_fixed(c.x) / mass;
+    float vy = decode_fixed(c.y) / mass;
+    float vz = decode_fixed(c.z) / mass;
+    if (x < 2 || x > P.gx - 2) vx = 0.0f;
+    if (y < 2 || y > P.gy - 2) vy = 0.0f;
+    if (z < 2 || z > P.gz - 2) vz = 0.0f;
+    cellf[i] = make_float4(vx, vy, vz, mass);
+}
+
 __global__ void __launch_bounds__(256)
 update_grid_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass_i,
                    const int *__restrict__ mass_of_cellf, float4 *__restrict__ cellf, long long cells, Params P)
@@ -193,23 +219,10 @@ update_grid_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass_i
     long long stride = (long long)gridDim.x * blockDim.x;
     const int plane = P.gy * P.gz;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
-        const int before = mass_of_cellf[i];
-        float mass = decode_fixed(mass_i[i]);
-        if (!(mass > 0.0f)) {
-            if (before > 0) cellf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            continue;
-        }
-        int4 c = cell[i];
-        float vx = decode_fixed(c.x) / mass;
-        float vy = decode_fixed(c.y) / mass;
-        float vz = decode_fixed(c.z) / mass;
         int lx = (int)(i / plane);
         int rem = (int)(i - (long long)lx * plane);
-        int x = lx + P.x_off, y = rem / P.gz, z = rem - y * P.gz;
-        if (x < 2 || x > P.gx - 2) vx = 0.0f;
-        if (y < 2 || y > P.gy - 2) vy = 0.0f;
-        if (z < 2 || z > P.gz - 2) vz = 0.0f;
-        cellf[i] = make_float4(vx, vy, vz, mass);
+        int y = rem / P.gz;
+        update_grid_cell(cell, mass_i, mass_of_cellf, cellf, i, lx + P.x_off, y, rem - y * P.gz, P);
     }
 }
 

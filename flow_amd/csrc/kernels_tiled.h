@@ -309,6 +309,59 @@ __device__ __forceinline__ void add_straggler(const Stragglers &sg, int j)
 // Adds every non-zero word of an LDS arena component to the global grid.  A wave
 // instruction covers (component, consecutive cells) so that its 64 atomics fall
 // in runs of contiguous 16-byte cell records.
+// Which of the 27 tiles an arena overlaps the 3x3x3 stencil with arena base (bx, by, bz) reaches:
+// bit (ox * 3 + oy) * 3 + oz with o = 0, 1, 2 for the tile before, the arena's own tile, the tile
+// after.  Per axis the stencil spans cells b .. b + 2, hence one or two of the three.
+__device__ __forceinline__ unsigned stencil_tile_bits(int bx, int by, int bz)
+{
+    auto axis = [](int b, int tile_size) -> unsigned {          // 3-bit set of tile offsets
+        const int lo = b < kRim ? 0 : (b < kRim + tile_size ? 1 : 2);
+        const int hi = b + 2 < kRim ? 0 : (b + 2 < kRim + tile_size ? 1 : 2);
+        return (1u << lo) | (1u << hi);
+    };
+    auto spread = [](unsigned m, int by_bits) -> unsigned {     // bit k of m -> bit k * by_bits
+        return (m & 1u) | ((m & 2u) << (by_bits - 1)) | ((m & 4u) << (2 * by_bits - 2));
+    };
+    const unsigned z = axis(bz, kTZ);
+    const unsigned yz = z * spread(axis(by, kTY), 3);           // no carries: the factors' bits do not overlap
+    return yz * spread(axis(bx, kTX), 9);
+}
+
+// `touched` holds, per thread, the stencil_tile_bits of every particle it scattered into the
+// arena of `tile`.  Sets g.dirty_bits on those tiles.  All threads of the workgroup call it.
+__device__ __forceinline__ void mark_dirty_tiles(unsigned touched, int tile, TileDims td, const FixedGrid &g)
+{
+    if (!g.dirty) return;                   // uniform
+    __shared__ unsigned touched_all;
+    if (threadIdx.x == 0) touched_all = 0;
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) touched |= __shfl_xor(touched, off);
+    if ((threadIdx.x & 63) == 0 && touched) atomicOr(&touched_all, touched);
+    __syncthreads();
+    if (threadIdx.x < 27 && (touched_all >> threadIdx.x & 1u)) {
+        const int tz = tile % td.tiles_z, ty = (tile / td.tiles_z) % td.tiles_y, tx = tile / (td.tiles_z * td.tiles_y);
+        const int k = threadIdx.x;
+        const int nx = tx + k / 9 - 1, ny = ty + (k / 3) % 3 - 1, nz = tz + k % 3 - 1;
+        // a cell that exists lies in a tile that exists
+        atomicOr(&g.dirty[(nx * td.tiles_y + ny) * td.tiles_z + nz], g.dirty_bits);
+    }
+}
+
+// Sets g.dirty_bits on the (up to 8) tiles the 27 cells of a stencil lie in.
+__device__ __forceinline__ void mark_dirty_stencil(const Stencil &s, TileDims td, const Params &P, const FixedGrid &g)
+{
+    if (!g.dirty) return;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int cx = s.cx + (k & 4 ? 2 : 0), cy = s.cy + (k & 2 ? 2 : 0), cz = s.cz + (k & 1 ? 2 : 0);
+        const int lx = cx - P.x_off;
+        if ((unsigned)lx >= (unsigned)P.local_nx || (unsigned)cy >= (unsigned)P.gy || (unsigned)cz >= (unsigned)P.gz)
+            continue;
+        atomicOr(&g.dirty[((lx / kTX) * td.tiles_y + cy / kTY) * td.tiles_z + cz / kTZ], g.dirty_bits);
+    }
+}
+
 template <int NCOMP>
 __device__ __forceinline__ void flush_arena(const int *lds, const Arena &A, const Params &P,
                                             FixedGrid g)
@@ -419,6 +472,7 @@ p2g1_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     for (int i = threadIdx.x; i < 4 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     __syncthreads();
 
+    unsigned touched = 0;      // see p2g_mass_tiled_kernel; p2g2 covers the same cells
     for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
         float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
         float vx = st.slot(kVelX)[j], vy = st.slot(kVelY)[j], vz = st.slot(kVelZ)[j];
@@ -427,13 +481,15 @@ p2g1_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         for (int k = 0; k < 9; k++) C[k] = st.slot(kC00 + k)[j];
         Stencil s = make_stencil(px, py, pz);
         int abase;
-        if (stencil_in_arena(s, A, &abase))
+        if (stencil_in_arena(s, A, &abase)) {
             p2g1_particle<true>(s, vx, vy, vz, C, lds, abase, g, P);
-        else
+            touched |= stencil_tile_bits(s.cx - A.ox, s.cy - A.oy, s.cz - A.oz);
+        } else
             add_straggler(sg, j);
     }
     __syncthreads();
     flush_arena<4>(lds, A, P, g);
+    mark_dirty_tiles(touched, item.x, w.td, g);
 }
 
 // ---- p2g2 (SIM:336-392) ------------------------------------------------------------
@@ -578,12 +634,16 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < kArenaCells; i += kTiledThreads) lds[i] = 0;
     __syncthreads();
+    // The tiles this work item adds to, for clearGrid and updateGrid (FixedGrid::dirty).  The
+    // momentum pass scatters the same particles over the same cells and marks nothing.
+    unsigned touched = 0;
     for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
         Stencil s = make_stencil(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j]);
         int abase;
-        if (stencil_in_arena(s, A, &abase))
+        if (stencil_in_arena(s, A, &abase)) {
             p2g_mass_particle<true>(s, lds, abase, g, P);
-        else
+            touched |= stencil_tile_bits(s.cx - A.ox, s.cy - A.oy, s.cz - A.oz);
+        } else
             add_straggler(sg, j);
     }
     __syncthreads();
@@ -593,6 +653,7 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         long long c = arena_cell_to_grid(a, A, P);
         if (c >= 0) atomicAdd(g.mass + c, v);
     }
+    mark_dirty_tiles(touched, item.x, w.td, g);
 }
 
 template <bool INSIDE>
@@ -890,6 +951,7 @@ straggler_p2g_kernel(TiledWork w, FixedGrid g, Params P)
 #pragma unroll
         for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
         Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
+        mark_dirty_stencil(s, w.td, P, g);
         if (PASS == 0) p2g1_particle<false>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, nullptr, 0, g, P);
         if (PASS == 1) p2g2_particle<false>(s, in + kC00, st.slot(kDensity) + j, nullptr, nullptr, 0, g, P);
         if (PASS == 2) p2g_mass_particle<false>(s, nullptr, 0, g, P);
@@ -941,6 +1003,72 @@ straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
         st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;
         st.slot(kVelX)[j] = o.vx; st.slot(kVelY)[j] = o.vy; st.slot(kVelZ)[j] = o.vz;
         st.slot(kDirX)[j] = o.dirx; st.slot(kDirY)[j] = o.diry; st.slot(kDirZ)[j] = o.dirz;
+    }
+}
+
+// ---- clearGrid and updateGrid over the dirty tiles only --------------------------------
+//
+// FixedGrid::dirty says which tiles may hold a non-zero word in which buffer.  One workgroup per
+// tile; a tile whose bits are clear costs one load.  Tiles with tx <= always_lo or
+// tx >= always_hi are treated as dirty whatever their bits: a slab's boundary planes also
+// receive the neighbours' contributions, which set no bits.
+
+struct TileRange { int always_lo, always_hi; };
+
+__device__ __forceinline__ bool tile_always(int tile, TileDims td, TileRange r)
+{
+    const int tx = tile / (td.tiles_z * td.tiles_y);
+    return tx <= r.always_lo || tx >= r.always_hi;
+}
+
+// Local linear index of cell k (0..511) of a tile, or -1 outside the grid.
+__device__ __forceinline__ long long tile_cell(int tile, int k, TileDims td, const Params &P, int *lx, int *y, int *z)
+{
+    const int tz = tile % td.tiles_z, ty = (tile / td.tiles_z) % td.tiles_y, tx = tile / (td.tiles_z * td.tiles_y);
+    *z = tz * kTZ + (k & 7);
+    *y = ty * kTY + ((k >> 3) & 7);
+    *lx = tx * kTX + (k >> 6);
+    if (*lx >= P.local_nx || *y >= P.gy || *z >= P.gz) return -1;
+    return ((long long)*lx * P.gy + *y) * P.gz + *z;
+}
+
+// clearGrid of the fixed-point grid (SIM:262-277 without the float grid): the momentum records
+// of tiles with bit 0 set, the words of mass buffer `mass` of tiles with `mass_bit` set; both
+// bits are cleared.
+__global__ void __launch_bounds__(256)
+clear_tiles_kernel(int4 *__restrict__ cell, int *__restrict__ mass, int *__restrict__ dirty, int mass_bit,
+                   TileDims td, Params P, TileRange r)
+{
+    const int t = blockIdx.x;
+    const bool always = tile_always(t, td, r);
+    const int bits = dirty[t];
+    const bool do_cell = always || (bits & 1), do_mass = always || (bits & mass_bit);
+    if (!do_cell && !do_mass) return;
+    for (int k = threadIdx.x; k < kTX * kTY * kTZ; k += 256) {
+        int lx, y, z;
+        const long long c = tile_cell(t, k, td, P, &lx, &y, &z);
+        if (c < 0) continue;
+        if (do_cell) cell[c] = make_int4(0, 0, 0, 0);
+        if (do_mass) mass[c] = 0;
+    }
+    __syncthreads();                       // every thread has read the bits
+    if (threadIdx.x == 0) dirty[t] = bits & ~(1 | mass_bit);
+}
+
+// updateGrid (SIM:395-429, see update_grid_kernel) over the tiles where this step's mass buffer
+// or the one that describes the float grid may be non-zero (`bits`).
+__global__ void __launch_bounds__(256)
+update_grid_tiles_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass_i,
+                         const int *__restrict__ mass_of_cellf, float4 *__restrict__ cellf,
+                         const int *__restrict__ dirty, int bits, TileDims td, Params P, TileRange r)
+{
+    const int t = blockIdx.x;
+    if (!(tile_always(t, td, r) || (dirty[t] & bits))) return;
+    for (int k = threadIdx.x; k < kTX * kTY * kTZ; k += 256) {
+        int lx, y, z;
+        const long long i = tile_cell(t, k, td, P, &lx, &y, &z);
+        if (i < 0) continue;
+        update_grid_cell(cell, mass_i, mass_of_cellf, cellf, i, lx + P.x_off, y, z, P);
     }
 }
 

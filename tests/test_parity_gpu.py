@@ -157,6 +157,32 @@ def test_long_run_on_one_binning(oracle_binding, monkeypatch, case):
     h.close()
 
 
+def test_tile_bits_survive_a_change_of_particles_between_the_p2g_passes(oracle_binding):
+    """clearGrid and updateGrid only visit the tiles the mass pass marked.  When the particle set
+    is replaced between the two p2g passes (here: by itself, which still forces a re-bin) the
+    marks no longer vouch for the momentum pass, and the device has to fall back to visiting
+    every tile -- over several steps, so that a skipped tile would show as stale grid words."""
+    grid, n = (40, 24, 24), 6000
+    rec = moving_particles(n, grid, seed=31, vel=2.0)
+    h = _handle(grid, rec, _lib.ALGO_TILED)
+    orc = oracle_binding.Oracle(grid)
+    want = rec.copy()
+    u = oracle_binding.make_uniforms(grid, n, **DEFAULT_UNIFORMS)
+    for k in range(6):
+        h.run_kernel(_lib.KERNEL_CLEAR_FIXED_GRID)
+        h.run_kernel(_lib.KERNEL_P2G_MASS)
+        if k % 2 == 1:
+            h.upload_particles(h.download_particles())
+        h.run_kernel(_lib.KERNEL_P2G_MOMENTUM)
+        h.run_kernel(_lib.KERNEL_UPDATE_GRID)
+        h.run_kernel(_lib.KERNEL_G2P)
+        orc.run(want, u, 1, 0.0)
+        assert np.array_equal(h.download_grid_i32(), orc.cell), "fixed-point grid at step %d" % k
+        assert_bits_equal(h.download_grid_f32(), orc.cellf, "float grid at step %d" % k)
+    assert_bits_equal(h.download_particles(), want, "particles")
+    h.close()
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 def test_clear_of_the_fixed_grid_alone(oracle_binding, algo):
     """clearGrid without the float grid: updateGrid has to zero the float cells the fluid has
