@@ -18,6 +18,8 @@ TIMING_REBIN, TIMING_REBINS_DONE, TIMING_SLOTS = 5, 6, 8
 ALGO_SCATTER, ALGO_TILED, ALGO_TILED_UNFUSED = 0, 1, 2
 KERNEL_P2G_MASS, KERNEL_P2G_MOMENTUM = 16, 17
 KERNEL_CLEAR_FIXED_GRID = 18     # clearGrid without the float grid (updateGrid then keeps it)
+# slab handles: the mass pass split around particle migration (include/flowmpm.h)
+KERNEL_P2G_MASS_STAYERS, KERNEL_P2G_MASS_ARRIVALS = 19, 20
 FIELD_POSITION, FIELD_VELOCITY, FIELD_DENSITY, FIELD_COLOR, FIELD_DIRECTION, FIELD_MASS = range(6)
 FIELD_WIDTH = {FIELD_POSITION: 3, FIELD_VELOCITY: 3, FIELD_DENSITY: 1, FIELD_COLOR: 3,
                FIELD_DIRECTION: 3, FIELD_MASS: 1}

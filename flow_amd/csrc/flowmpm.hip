@@ -63,6 +63,10 @@ struct flowmpm_sim {
     // pass scatter the same particles over the same cells and rely on that.  False whenever that
     // is not known to hold (after a clear, a g2p, or any change of the particle set).
     bool tiles_marked = false;
+    // Slab handles: first slot of the particles inserted since the stayers' mass pass (-1: none),
+    // and whether that pass has run on the current particles.
+    long long arrivals_first = -1;
+    bool stayers_done = false;
     int mass_bit(const int *buffer) const { return buffer == mass_first ? 2 : 4; }
     mpm::FixedGrid fixed() const
     {
@@ -274,24 +278,52 @@ int stage_p2g2(flowmpm_sim *s)
 
 inline bool is_tiled(const flowmpm_sim *s) { return s->cfg.algorithm != FLOWMPM_ALGO_SCATTER; }
 
-// The two-pass p2g of the tiled algorithm; `momentum` selects the pass.
-int stage_p2g_pass(flowmpm_sim *s, bool momentum)
+// The two-pass p2g of the tiled algorithm; `momentum` selects the pass.  stayers_only: the mass
+// pass without the particles that have left the slab's owned planes.
+int stage_p2g_pass(flowmpm_sim *s, bool momentum, bool stayers_only = false)
 {
     int rc;
     if (!is_tiled(s)) return fail(s, FLOWMPM_ERR_INVALID, "the mass/momentum passes belong to the tiled algorithm");
+    if (stayers_only && !s->slab) return fail(s, FLOWMPM_ERR_INVALID, "the stayers' mass pass is for slab handles");
     if ((rc = stage_rebin_if_needed(s))) return rc;
+    if (stayers_only) {
+        s->stayers_done = true;
+        s->arrivals_first = -1;
+    }
     if (s->live > 0) {
         if (momentum && (rc = assume_all_tiles_dirty_unless_marked(s))) return rc;
         TimedLaunch t;
         if ((rc = timing_events(s, momentum ? FLOWMPM_KERNEL_P2G2 : FLOWMPM_KERNEL_P2G1, &t))) return rc;
+        const int keep_lo = stayers_only ? s->cfg.slab_x0 : -2147483647 - 1;
+        const int keep_hi = stayers_only ? s->cfg.slab_x0 + s->cfg.slab_nx : 2147483647;
         rc = momentum ? mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream,
                                                        t.start, t.stop)
                       : mpm::launch_p2g_mass_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream,
-                                                   t.start, t.stop);
+                                                   t.start, t.stop, keep_lo, keep_hi);
         if (rc) return fail(s, FLOWMPM_ERR_HIP, "p2g pass: could not reset the straggler counter");
         if ((rc = launch_check(s, momentum ? "p2g_momentum" : "p2g_mass"))) return rc;
         if (!momentum) s->tiles_marked = true;
     }
+    return FLOWMPM_OK;
+}
+
+// The mass contributions of the particles inserted since the stayers' mass pass.
+int stage_p2g_mass_arrivals(flowmpm_sim *s)
+{
+    if (!is_tiled(s) || !s->slab) return fail(s, FLOWMPM_ERR_INVALID, "the arrivals' mass pass is for tiled slab handles");
+    if (!s->stayers_done) return fail(s, FLOWMPM_ERR_INVALID, "P2G_MASS_ARRIVALS without P2G_MASS_STAYERS");
+    s->stayers_done = false;
+    const long long first = s->arrivals_first;
+    s->arrivals_first = -1;
+    if (first >= 0 && first < s->live) {
+        const long long count = s->live - first;
+        hipLaunchKernelGGL(mpm::p2g_mass_range_kernel, dim3((unsigned)std::min<long long>(blocks_for(count, 256), 1024)),
+                           dim3(256), 0, s->stream, s->store, (int)first, (int)s->live, s->fixed(), s->params,
+                           mpm::tile_dims(s->tiled));
+        int rc = launch_check(s, "p2g_mass_arrivals");
+        if (rc) return rc;
+    }
+    s->tiles_marked = true;      // stayers and arrivals together are the resident particles
     return FLOWMPM_OK;
 }
 
@@ -664,6 +696,8 @@ int flowmpm_run_kernel(flowmpm_sim *s, int32_t kernel_id)
     case FLOWMPM_KERNEL_G2P: return stage_g2p(s);
     case FLOWMPM_KERNEL_P2G_MASS: return stage_p2g_pass(s, false);
     case FLOWMPM_KERNEL_P2G_MOMENTUM: return stage_p2g_pass(s, true);
+    case FLOWMPM_KERNEL_P2G_MASS_STAYERS: return stage_p2g_pass(s, false, true);
+    case FLOWMPM_KERNEL_P2G_MASS_ARRIVALS: return stage_p2g_mass_arrivals(s);
     default: return fail(s, FLOWMPM_ERR_INVALID, "unknown kernel id");
     }
 }
@@ -1004,7 +1038,7 @@ int flowmpm_find_leavers(flowmpm_sim *s, const int32_t *plane_starts, int32_t n_
 {
     CHECK_SIM(s);
     if (!s->slab) return fail(s, FLOWMPM_ERR_INVALID, "not a slab handle");
-    if (!plane_starts || n_ranks < 1 || n_ranks > mpm::kMaxRanks || !dev_counts)
+    if (!plane_starts || n_ranks < 1 || n_ranks > mpm::kMaxRanks)
         return fail(s, FLOWMPM_ERR_INVALID, "bad rank table");
     std::string msg;
     if (mpm::find_leavers(s->migration, s->store, s->resident, s->cfg.slab_x0, s->cfg.slab_nx, plane_starts, n_ranks,
@@ -1045,6 +1079,7 @@ int flowmpm_insert_arrivals(flowmpm_sim *s, const void *dev_in, int64_t count)
                        reinterpret_cast<const float *>(dev_in), s->store, (long long)s->resident, (long long)count);
     int rc = launch_check(s, "insert_arrivals");
     if (rc) return rc;
+    if (s->stayers_done && s->arrivals_first < 0) s->arrivals_first = s->resident;
     s->resident += count;
     s->live = s->resident;      // arrivals sit past the binned range until the next re-bin
     s->tiles_marked = false;

@@ -117,6 +117,10 @@ struct TiledWork {
     int n;                       // live particles: items are clipped to [0, n)
     TileDims td;
     Stragglers sg;
+    // Mass pass only: particles whose floor(x) is outside [keep_lo, keep_hi) are skipped.  A slab
+    // whose leavers have not been packed yet runs its mass pass this way (they are no longer its
+    // particles); everywhere else the range is everything.
+    int keep_lo, keep_hi;
 };
 
 __device__ __forceinline__ int tile_of(float px, float py, float pz, const Params &P, TileDims td)
@@ -639,6 +643,7 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     unsigned touched = 0;
     for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
         Stencil s = make_stencil(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j]);
+        if (s.cx + 1 < w.keep_lo || s.cx + 1 >= w.keep_hi) continue;       // s.cx = floor(x) - 1
         int abase;
         if (stencil_in_arena(s, A, &abase)) {
             p2g_mass_particle<true>(s, lds, abase, g, P);
@@ -951,6 +956,7 @@ straggler_p2g_kernel(TiledWork w, FixedGrid g, Params P)
 #pragma unroll
         for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
         Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
+        if (PASS == 2 && (s.cx + 1 < w.keep_lo || s.cx + 1 >= w.keep_hi)) continue;
         mark_dirty_stencil(s, w.td, P, g);
         if (PASS == 0) p2g1_particle<false>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, nullptr, 0, g, P);
         if (PASS == 1) p2g2_particle<false>(s, in + kC00, st.slot(kDensity) + j, nullptr, nullptr, 0, g, P);
@@ -1153,7 +1159,7 @@ inline TiledWork tiled_work(TiledState &T, StoreSel ss, long long n)
     const Stragglers sg{T.straggler_counts + T.stage_parity, T.straggler_counts + (T.stage_parity ^ 1),
                         T.straggler_list};
     T.stage_parity ^= 1;
-    return TiledWork{ss, T.items, T.n_items, T.ctl, (int)n, tile_dims(T), sg};
+    return TiledWork{ss, T.items, T.n_items, T.ctl, (int)n, tile_dims(T), sg, -2147483647 - 1, 2147483647};
 }
 
 // Upper bound of the work items any binning of n particles can produce.
@@ -1188,10 +1194,31 @@ inline int launch_p2g2_tiled(TiledState &T, StoreSel st, long long n, FixedGrid 
     FLOWMPM_TILED_STAGE(p2g2_tiled_kernel, straggler_p2g_kernel<1>, g);
 }
 
+// keep_lo / keep_hi: see TiledWork.
 inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream,
-                             hipEvent_t ev_start, hipEvent_t ev_stop)
+                                 hipEvent_t ev_start, hipEvent_t ev_stop, int keep_lo = -2147483647 - 1,
+                                 int keep_hi = 2147483647)
 {
-    FLOWMPM_TILED_STAGE(p2g_mass_tiled_kernel, straggler_p2g_kernel<2>, g);
+    TiledWork w = tiled_work(T, st, n);
+    w.keep_lo = keep_lo;
+    w.keep_hi = keep_hi;
+    hipExtLaunchKernelGGL(p2g_mass_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, ev_start,
+                          ev_stop, 0, w, g, P);
+    hipLaunchKernelGGL(straggler_p2g_kernel<2>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
+    return 0;
+}
+
+// The mass pass for the particles in slots [first, n) alone (a slab's arrivals, inserted after
+// its mass pass ran), straight to the global grid.
+__global__ void __launch_bounds__(256)
+p2g_mass_range_kernel(StoreSel ss, int first, int n, FixedGrid g, Params P, TileDims td)
+{
+    const Store st = ss.pick();
+    for (int j = first + blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        Stencil s = make_stencil(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j]);
+        mark_dirty_stencil(s, td, P, g);
+        p2g_mass_particle<false>(s, nullptr, 0, g, P);
+    }
 }
 
 inline int launch_p2g_momentum_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P,

@@ -166,6 +166,11 @@ class GpuSlabBackend:
         self.handle.find_leavers(plane_starts, self._counts.data_ptr())
         return self._counts
 
+    def refind_leavers(self, plane_starts):
+        """The classification again, on the slots the particles occupy now (a re-bin may have
+        moved them since find_leavers); the counts are the same and are not exported again."""
+        self.handle.find_leavers(plane_starts, 0)
+
     def pack_leavers(self, counts):
         self.handle.pack_leavers(counts, self._leavers.data_ptr(), self._leavers.shape[0])
         return self._leavers[: int(np.asarray(counts).sum())]
@@ -206,6 +211,9 @@ class SlabSimulation:
                             else (_lib.KERNEL_P2G1, _lib.KERNEL_P2G2))
         # the device library's updateGrid keeps the float grid, so only the fixed-point grid is cleared
         self.clear_kernel = _lib.KERNEL_CLEAR_FIXED_GRID if backend is None else _lib.KERNEL_CLEAR_GRID
+        # The library's tiled mass pass can skip the leavers itself and add the arrivals later, so it
+        # is enqueued before the host waits for the migration counts.
+        self.split_mass_pass = fused and world > 1
         self.low = rank - 1 if rank > 0 else None
         self.high = rank + 1 if rank < world - 1 else None
         b = self.backend
@@ -342,8 +350,17 @@ class SlabSimulation:
         b = self.backend
         p2g = self.p2g_kernels
         b.run_kernel(self.clear_kernel)           # touches no particle: runs while the counts travel
-        self._finish_migration()
-        b.run_kernel(p2g[0])
+        if self.split_mass_pass:
+            # so does the mass pass of the particles that stay; the leavers are skipped on the
+            # device, the arrivals added once they are in
+            b.run_kernel(_lib.KERNEL_P2G_MASS_STAYERS)
+            if self._pending_counts is not None:
+                b.refind_leavers(self.plane_starts)
+            self._finish_migration()
+            b.run_kernel(_lib.KERNEL_P2G_MASS_ARRIVALS)
+        else:
+            self._finish_migration()
+            b.run_kernel(p2g[0])
         self._exchange_planes(_lib.COMP_MASS)
         b.run_kernel(p2g[1])
         self._exchange_planes(_lib.COMP_MOMENTUM)

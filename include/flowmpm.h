@@ -54,6 +54,14 @@ extern "C" {
  * grid equals the reference's bit for bit.  Timed as FLOWMPM_KERNEL_CLEAR_GRID.  flowmpm_step
  * uses this form. */
 #define FLOWMPM_KERNEL_CLEAR_FIXED_GRID 18
+/* Slab handles of the tiled algorithm: the mass pass split around particle migration, so that it
+ * can be enqueued before the host knows the migration counts.  _STAYERS is FLOWMPM_KERNEL_P2G_MASS
+ * over the resident particles except those whose floor(x) has left the slab's owned planes (the
+ * leavers flowmpm_pack_leavers will remove); _ARRIVALS adds the particles inserted by
+ * flowmpm_insert_arrivals since then.  Together they leave the grid FLOWMPM_KERNEL_P2G_MASS would
+ * leave after the migration.  Both are timed as FLOWMPM_KERNEL_P2G1. */
+#define FLOWMPM_KERNEL_P2G_MASS_STAYERS  19
+#define FLOWMPM_KERNEL_P2G_MASS_ARRIVALS 20
 
 /* Timing slots reported by flowmpm_get_timings: the five kernels, then the
  * particle re-binning pass of the tiled algorithm (no reference counterpart). */
@@ -286,7 +294,9 @@ int flowmpm_extract_leavers(flowmpm_sim *sim, const int32_t *plane_starts, int32
  * classification; the n_ranks leaver counts appear as int64 words in `dev_counts` (device
  * memory of the caller) in stream order.  flowmpm_pack_leavers takes those counts back from
  * the caller (host memory) once it has read them, packs the records and compacts the store.
- * No step may run between the two calls. */
+ * Between the two calls only clearGrid and FLOWMPM_KERNEL_P2G_MASS_STAYERS may run; as that stage
+ * may re-bin (move) the particles, flowmpm_find_leavers is then called once more before the pack
+ * (dev_counts may be NULL: the counts are the same). */
 int flowmpm_find_leavers(flowmpm_sim *sim, const int32_t *plane_starts, int32_t n_ranks, void *dev_counts);
 int flowmpm_pack_leavers(flowmpm_sim *sim, const int64_t *counts, int32_t n_ranks, void *dev_out,
                          int64_t capacity_records);
