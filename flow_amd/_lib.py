@@ -20,6 +20,10 @@ KERNEL_P2G_MASS, KERNEL_P2G_MOMENTUM = 16, 17
 KERNEL_CLEAR_FIXED_GRID = 18     # clearGrid without the float grid (updateGrid then keeps it)
 # slab handles: the mass pass split around particle migration (include/flowmpm.h)
 KERNEL_P2G_MASS_STAYERS, KERNEL_P2G_MASS_ARRIVALS = 19, 20
+# slab handles: momentum pass and g2p in an interior and a boundary launch, updateGrid again over the
+# boundary tiles (include/flowmpm.h)
+KERNEL_P2G_MOMENTUM_INTERIOR, KERNEL_P2G_MOMENTUM_BOUNDARY = 21, 22
+KERNEL_G2P_INTERIOR, KERNEL_G2P_BOUNDARY, KERNEL_UPDATE_GRID_BOUNDARY = 23, 24, 25
 FIELD_POSITION, FIELD_VELOCITY, FIELD_DENSITY, FIELD_COLOR, FIELD_DIRECTION, FIELD_MASS = range(6)
 FIELD_WIDTH = {FIELD_POSITION: 3, FIELD_VELOCITY: 3, FIELD_DENSITY: 1, FIELD_COLOR: 3,
                FIELD_DIRECTION: 3, FIELD_MASS: 1}

@@ -27,6 +27,7 @@ thread_local std::string g_last_error;
 struct EventPair {
     hipEvent_t start, stop;
     int slot;
+    bool continuation;      // second launch of one stage: adds its time, not a launch
 };
 
 }  // namespace
@@ -73,6 +74,13 @@ struct flowmpm_sim {
         return mpm::FixedGrid{reinterpret_cast<int *>(cell), mass_i, dirty, 1 | mass_bit(mass_i)};
     }
     // a slab's boundary planes receive the neighbours' contributions too, which set no bits
+    // Work items whose arena reaches the planes a halo exchange changes (local planes 0, 1,
+    // slab_nx, slab_nx + 1; an arena spans 8 tx - 2 .. 8 tx + 9): tile x index 0, and from
+    // (slab_nx - 2) / 8 on.
+    mpm::StagePart stage_part(int part) const
+    {
+        return mpm::StagePart{part, 0, std::max(cfg.slab_nx - 2, 0) / mpm::kTX};
+    }
     mpm::TileRange tile_range() const
     {
         return slab ? mpm::TileRange{0, cfg.slab_nx / mpm::kTX} : mpm::TileRange{-1, 1 << 30};
@@ -153,7 +161,7 @@ void refresh_params(flowmpm_sim *s)
 // the schedule of the step as it is, and the durations are the ones a kernel trace reports.
 struct TimedLaunch { hipEvent_t start = nullptr, stop = nullptr; };
 
-int timing_events(flowmpm_sim *s, int slot, TimedLaunch *out)
+int timing_events(flowmpm_sim *s, int slot, TimedLaunch *out, bool continuation = false)
 {
     *out = TimedLaunch{};
     if (!s->profiling) return FLOWMPM_OK;
@@ -165,6 +173,7 @@ int timing_events(flowmpm_sim *s, int slot, TimedLaunch *out)
     }
     EventPair &p = s->events[s->events_used++];
     p.slot = slot;
+    p.continuation = continuation;
     out->start = p.start;
     out->stop = p.stop;
     return FLOWMPM_OK;
@@ -178,7 +187,7 @@ int timing_collect(flowmpm_sim *s)
         float ms = 0.0f;
         HIP_TRY(s, hipEventElapsedTime(&ms, s->events[i].start, s->events[i].stop));
         s->timings.ms[s->events[i].slot] += ms;
-        s->timings.launches[s->events[i].slot] += 1;
+        if (!s->events[i].continuation) s->timings.launches[s->events[i].slot] += 1;
     }
     s->events_used = 0;
     return FLOWMPM_OK;
@@ -280,11 +289,12 @@ inline bool is_tiled(const flowmpm_sim *s) { return s->cfg.algorithm != FLOWMPM_
 
 // The two-pass p2g of the tiled algorithm; `momentum` selects the pass.  stayers_only: the mass
 // pass without the particles that have left the slab's owned planes.
-int stage_p2g_pass(flowmpm_sim *s, bool momentum, bool stayers_only = false)
+int stage_p2g_pass(flowmpm_sim *s, bool momentum, bool stayers_only = false, int part = 0)
 {
     int rc;
     if (!is_tiled(s)) return fail(s, FLOWMPM_ERR_INVALID, "the mass/momentum passes belong to the tiled algorithm");
     if (stayers_only && !s->slab) return fail(s, FLOWMPM_ERR_INVALID, "the stayers' mass pass is for slab handles");
+    if (part != 0 && !s->slab) return fail(s, FLOWMPM_ERR_INVALID, "interior / boundary parts are for slab handles");
     if ((rc = stage_rebin_if_needed(s))) return rc;
     if (stayers_only) {
         s->stayers_done = true;
@@ -293,11 +303,11 @@ int stage_p2g_pass(flowmpm_sim *s, bool momentum, bool stayers_only = false)
     if (s->live > 0) {
         if (momentum && (rc = assume_all_tiles_dirty_unless_marked(s))) return rc;
         TimedLaunch t;
-        if ((rc = timing_events(s, momentum ? FLOWMPM_KERNEL_P2G2 : FLOWMPM_KERNEL_P2G1, &t))) return rc;
+        if ((rc = timing_events(s, momentum ? FLOWMPM_KERNEL_P2G2 : FLOWMPM_KERNEL_P2G1, &t, part == 2))) return rc;
         const int keep_lo = stayers_only ? s->cfg.slab_x0 : -2147483647 - 1;
         const int keep_hi = stayers_only ? s->cfg.slab_x0 + s->cfg.slab_nx : 2147483647;
         rc = momentum ? mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream,
-                                                       t.start, t.stop)
+                                                       t.start, t.stop, s->stage_part(part))
                       : mpm::launch_p2g_mass_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream,
                                                    t.start, t.stop, keep_lo, keep_hi);
         if (rc) return fail(s, FLOWMPM_ERR_HIP, "p2g pass: could not reset the straggler counter");
@@ -327,17 +337,19 @@ int stage_p2g_mass_arrivals(flowmpm_sim *s)
     return FLOWMPM_OK;
 }
 
-int stage_update_grid(flowmpm_sim *s)
+int stage_update_grid(flowmpm_sim *s, bool boundary_only = false)
 {
+    if (boundary_only && !(s->slab && s->dirty))
+        return fail(s, FLOWMPM_ERR_INVALID, "UPDATE_GRID_BOUNDARY is for tiled slab handles");
     TimedLaunch t;
-    int rc = timing_events(s, FLOWMPM_KERNEL_UPDATE_GRID, &t);
+    int rc = timing_events(s, FLOWMPM_KERNEL_UPDATE_GRID, &t, boundary_only);
     if (rc) return rc;
     unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
     if (s->dirty)
         hipExtLaunchKernelGGL(mpm::update_grid_tiles_kernel, dim3(s->tiled.n_tiles), dim3(256), 0, s->stream, t.start,
                               t.stop, 0, s->cell, s->mass_i, s->mass_of_cellf, s->cellf, s->dirty,
-                              s->mass_bit(s->mass_i) | s->mass_bit(s->mass_of_cellf), mpm::tile_dims(s->tiled),
-                              s->params, s->tile_range());
+                              boundary_only ? -1 : (s->mass_bit(s->mass_i) | s->mass_bit(s->mass_of_cellf)),
+                              mpm::tile_dims(s->tiled), s->params, s->tile_range());
     else
         hipExtLaunchKernelGGL(mpm::update_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
                               s->cell, s->mass_i, s->mass_of_cellf, s->cellf, s->local_cells, s->params);
@@ -369,9 +381,11 @@ __global__ void store_modes_kernel(mpm::ModeParams value, mpm::ModeParams *dst)
     for (unsigned i = threadIdx.x; i < sizeof(mpm::ModeParams) / sizeof(unsigned); i += blockDim.x) out[i] = src[i];
 }
 
-int stage_g2p(flowmpm_sim *s)
+int stage_g2p(flowmpm_sim *s, int part = 0)
 {
     int rc;
+    if (part != 0 && !(s->slab && is_tiled(s)))
+        return fail(s, FLOWMPM_ERR_INVALID, "interior / boundary parts are for tiled slab handles");
     if (is_tiled(s) && (rc = stage_rebin_if_needed(s))) return rc;
     const mpm::ModeParams *modes = nullptr;
     if (any_mode_on(s)) {
@@ -392,12 +406,12 @@ int stage_g2p(flowmpm_sim *s)
     }
     if (s->live > 0) {
         TimedLaunch t;
-        if ((rc = timing_events(s, FLOWMPM_KERNEL_G2P, &t))) return rc;
+        if ((rc = timing_events(s, FLOWMPM_KERNEL_G2P, &t, part == 2))) return rc;
         if (is_tiled(s)) {
             if ((rc = mpm::launch_g2p_tiled(s->tiled, s->store, s->live, s->cellf, s->params, modes, s->stream,
-                                            t.start, t.stop)))
+                                            t.start, t.stop, s->stage_part(part))))
                 return fail(s, FLOWMPM_ERR_HIP, "g2p_tiled launch failed");
-            s->tiled.checked = false;      // the next step decides anew
+            if (part != 1) s->tiled.checked = false;      // the next step decides anew
             s->tiles_marked = false;       // the particles move
         } else if (modes) {
             hipExtLaunchKernelGGL(mpm::g2p_gather_kernel<true>, dim3(blocks_for(s->live, 256)), dim3(256), 0,
@@ -698,6 +712,11 @@ int flowmpm_run_kernel(flowmpm_sim *s, int32_t kernel_id)
     case FLOWMPM_KERNEL_P2G_MOMENTUM: return stage_p2g_pass(s, true);
     case FLOWMPM_KERNEL_P2G_MASS_STAYERS: return stage_p2g_pass(s, false, true);
     case FLOWMPM_KERNEL_P2G_MASS_ARRIVALS: return stage_p2g_mass_arrivals(s);
+    case FLOWMPM_KERNEL_P2G_MOMENTUM_INTERIOR: return stage_p2g_pass(s, true, false, 1);
+    case FLOWMPM_KERNEL_P2G_MOMENTUM_BOUNDARY: return stage_p2g_pass(s, true, false, 2);
+    case FLOWMPM_KERNEL_G2P_INTERIOR: return stage_g2p(s, 1);
+    case FLOWMPM_KERNEL_G2P_BOUNDARY: return stage_g2p(s, 2);
+    case FLOWMPM_KERNEL_UPDATE_GRID_BOUNDARY: return stage_update_grid(s, true);
     default: return fail(s, FLOWMPM_ERR_INVALID, "unknown kernel id");
     }
 }

@@ -121,6 +121,10 @@ struct TiledWork {
     // whose leavers have not been packed yet runs its mass pass this way (they are no longer its
     // particles); everywhere else the range is everything.
     int keep_lo, keep_hi;
+    // A stage may be launched in two parts: part 1 takes the work items of interior tiles
+    // (bnd_lo < tile x index < bnd_hi), part 2 the others; part 0 takes all.  A slab uses this to
+    // run the items that cannot see its boundary planes while those planes' halo is in flight.
+    int part, bnd_lo, bnd_hi;
 };
 
 __device__ __forceinline__ int tile_of(float px, float py, float pz, const Params &P, TileDims td)
@@ -408,6 +412,11 @@ __device__ __forceinline__ bool take_item(const TiledWork &w, int4 *item)
     if (id < 0) return false;
     *item = w.items[id];
     item->z = min(item->z, w.n);
+    if (w.part != 0) {
+        const int tx = item->x / (w.td.tiles_y * w.td.tiles_z);
+        const bool boundary = tx <= w.bnd_lo || tx >= w.bnd_hi;
+        if (boundary != (w.part == 2)) return false;
+    }
     return item->y < item->z;
 }
 
@@ -1068,8 +1077,9 @@ update_grid_tiles_kernel(const int4 *__restrict__ cell, const int *__restrict__ 
                          const int *__restrict__ mass_of_cellf, float4 *__restrict__ cellf,
                          const int *__restrict__ dirty, int bits, TileDims td, Params P, TileRange r)
 {
+    // bits < 0: the always-visited (boundary) tiles only
     const int t = blockIdx.x;
-    if (!(tile_always(t, td, r) || (dirty[t] & bits))) return;
+    if (!(tile_always(t, td, r) || (bits >= 0 && (dirty[t] & bits)))) return;
     for (int k = threadIdx.x; k < kTX * kTY * kTZ; k += 256) {
         int lx, y, z;
         const long long i = tile_cell(t, k, td, P, &lx, &y, &z);
@@ -1154,12 +1164,18 @@ inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P
 // The work description of the next stage.  Stages alternate between two straggler counters:
 // the follow-up kernel of a stage zeroes the one the next stage will count into, which saves a
 // memset launch per stage.
-inline TiledWork tiled_work(TiledState &T, StoreSel ss, long long n)
+// A stage launched in two parts (TiledWork::part) counts its stragglers in one counter: part 1
+// leaves the choice of counter to part 2, whose follow-up kernel handles what both listed.
+struct StagePart { int part, bnd_lo, bnd_hi; };
+constexpr StagePart kWholeStage{0, 0, 0};
+
+inline TiledWork tiled_work(TiledState &T, StoreSel ss, long long n, StagePart sp = kWholeStage)
 {
     const Stragglers sg{T.straggler_counts + T.stage_parity, T.straggler_counts + (T.stage_parity ^ 1),
                         T.straggler_list};
-    T.stage_parity ^= 1;
-    return TiledWork{ss, T.items, T.n_items, T.ctl, (int)n, tile_dims(T), sg, -2147483647 - 1, 2147483647};
+    if (sp.part != 1) T.stage_parity ^= 1;
+    return TiledWork{ss, T.items, T.n_items, T.ctl, (int)n, tile_dims(T), sg, -2147483647 - 1, 2147483647,
+                     sp.part, sp.bnd_lo, sp.bnd_hi};
 }
 
 // Upper bound of the work items any binning of n particles can produce.
@@ -1222,25 +1238,34 @@ p2g_mass_range_kernel(StoreSel ss, int first, int n, FixedGrid g, Params P, Tile
 }
 
 inline int launch_p2g_momentum_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P,
-                                     hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
+                                     hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
+                                     StagePart sp = kWholeStage)
 {
-    FLOWMPM_TILED_STAGE(p2g_momentum_tiled_kernel, straggler_p2g_kernel<3>, g);
+    const TiledWork w = tiled_work(T, st, n, sp);
+    hipExtLaunchKernelGGL(p2g_momentum_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream,
+                          ev_start, ev_stop, 0, w, g, P);
+    if (sp.part != 1)
+        hipLaunchKernelGGL(straggler_p2g_kernel<3>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
+    return 0;
 }
 
 // modes == nullptr: chaos path.
 inline int launch_g2p_tiled(TiledState &T, StoreSel st, long long n, const float4 *cellf, const Params &P,
-                            const ModeParams *modes, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
+                            const ModeParams *modes, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
+                            StagePart sp = kWholeStage)
 {
     const dim3 grid(item_bound(T, n)), block(kTiledThreads);
-    const TiledWork w = tiled_work(T, st, n);
+    const TiledWork w = tiled_work(T, st, n, sp);
     if (modes) {
         hipExtLaunchKernelGGL(g2p_tiled_kernel<true>, grid, block, 0, stream, ev_start, ev_stop, 0, w, cellf, P, modes);
-        hipLaunchKernelGGL(straggler_g2p_kernel<true>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, cellf, P,
-                           modes);
+        if (sp.part != 1)
+            hipLaunchKernelGGL(straggler_g2p_kernel<true>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, cellf, P,
+                               modes);
     } else {
         hipExtLaunchKernelGGL(g2p_tiled_kernel<false>, grid, block, 0, stream, ev_start, ev_stop, 0, w, cellf, P, modes);
-        hipLaunchKernelGGL(straggler_g2p_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, cellf, P,
-                           modes);
+        if (sp.part != 1)
+            hipLaunchKernelGGL(straggler_g2p_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, cellf, P,
+                               modes);
     }
     return 0;
 }

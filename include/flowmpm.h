@@ -62,6 +62,20 @@ extern "C" {
  * leave after the migration.  Both are timed as FLOWMPM_KERNEL_P2G1. */
 #define FLOWMPM_KERNEL_P2G_MASS_STAYERS  19
 #define FLOWMPM_KERNEL_P2G_MASS_ARRIVALS 20
+/* Slab handles of the tiled algorithm: the momentum pass and g2p in two launches, so that a halo
+ * exchange can be in flight during the first.  _INTERIOR runs the work items whose tile
+ * neighbourhood cannot reach the four planes a halo exchange changes (slab_x0 - 1, slab_x0,
+ * slab_x0 + slab_nx - 1, slab_x0 + slab_nx); _BOUNDARY runs the others and everything the tiled
+ * kernels leave to the follow-up kernel.  _INTERIOR then _BOUNDARY equals the whole stage.
+ * FLOWMPM_KERNEL_UPDATE_GRID_BOUNDARY is updateGrid over the tiles that hold those four planes
+ * again (updateGrid is a pure function of the fixed-point grid, so running it early over
+ * everything and once more over these tiles after the momentum halo has been added gives the
+ * float grid of a single late run). */
+#define FLOWMPM_KERNEL_P2G_MOMENTUM_INTERIOR 21
+#define FLOWMPM_KERNEL_P2G_MOMENTUM_BOUNDARY 22
+#define FLOWMPM_KERNEL_G2P_INTERIOR          23
+#define FLOWMPM_KERNEL_G2P_BOUNDARY          24
+#define FLOWMPM_KERNEL_UPDATE_GRID_BOUNDARY  25
 
 /* Timing slots reported by flowmpm_get_timings: the five kernels, then the
  * particle re-binning pass of the tiled algorithm (no reference counterpart). */

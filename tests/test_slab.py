@@ -203,14 +203,19 @@ def test_two_slabs_in_one_process_match_single_domain(oracle_binding, algo, plan
 
 
 @pytest.mark.gpu
-def test_two_rank_rehearsal_on_one_gpu(oracle_binding, tmp_path):
-    """Two processes, both on cuda:0, gloo transport with host staging: the whole
-    SlabSimulation code path of the multi-GPU benchmark except RCCL itself."""
-    grid, n, steps, vel = (24, 16, 12), 4000, 8, 3.0
-    _launch(2, tmp_path, "--backend", "gpu", "--grid", "24,16,12", "--particles", str(n),
+@pytest.mark.parametrize("grid,n,steps,vel", [((24, 16, 12), 4000, 8, 3.0),      # thin slabs: every tile is a boundary tile
+                                             ((112, 16, 16), 14000, 10, 3.0),   # 56 planes per slab: interior tiles too
+                                             ((3 * 40, 16, 16), 12000, 8, 3.0)])
+def test_two_rank_rehearsal_on_one_gpu(oracle_binding, tmp_path, grid, n, steps, vel):
+    """Two (three for the last case) processes, all on cuda:0, gloo transport with host
+    staging: the whole SlabSimulation code path of the multi-GPU benchmark except RCCL itself --
+    the mass pass split around the migration, momentum pass and g2p in an interior and a
+    boundary launch with the halo exchanges posted in between."""
+    world = 3 if grid[0] == 120 else 2
+    _launch(world, tmp_path, "--backend", "gpu", "--grid", "%d,%d,%d" % grid, "--particles", str(n),
             "--steps", str(steps), "--vel", str(vel))
     rec, orc = _reference_run(oracle_binding, grid, n, steps, vel)
-    moved = _check_against_single_domain(tmp_path, 2, rec, orc, grid)
+    moved = _check_against_single_domain(tmp_path, world, rec, orc, grid)
     assert moved > 0
 
 
