@@ -29,6 +29,8 @@ to the single-GPU grid for any number of slabs; tests assert exactly that.
 pieces) and to `torch.distributed`, so the protocol itself is exercised on CPU with the
 gloo backend in the tests, and runs on GPUs with `GpuSlabBackend`.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -225,7 +227,8 @@ class SlabSimulation:
         self.clear_kernel = _lib.KERNEL_CLEAR_FIXED_GRID if backend is None else _lib.KERNEL_CLEAR_GRID
         # The library's tiled mass pass can skip the leavers itself and add the arrivals later, so it
         # is enqueued before the host waits for the migration counts.
-        self.split_mass_pass = fused and world > 1
+        # (FLOWMPM_SLAB_OVERLAP=0 keeps every stage whole, for A/B runs on a multi-GPU node.)
+        self.split_mass_pass = fused and world > 1 and os.environ.get("FLOWMPM_SLAB_OVERLAP", "1") != "0"
         self.low = rank - 1 if rank > 0 else None
         self.high = rank + 1 if rank < world - 1 else None
         b = self.backend
@@ -404,250 +407,6 @@ class SlabSimulation:
         self._add_planes(_lib.COMP_MOMENTUM, momentum_halo)
         b.run_kernel(_lib.KERNEL_UPDATE_GRID_BOUNDARY)
         b.run_kernel(_lib.KERNEL_G2P_BOUNDARY)
-        self._begin_migration()
-
-    def resident(self):
-        return self.handle.num_particles()[1]
-
-    def new_plane_buffer(self, planes):
-        return torch.empty((planes, self.plane_words), dtype=torch.int32, device=self.torch_device)
-
-    def plane_read(self, plane, out):
-        self.handle.plane_copy_out(plane, out.data_ptr())
-
-    def plane_add(self, plane, src, mask):
-        self.handle.plane_add_i32(plane, src.data_ptr(), mask)
-
-    def new_halo_buffer(self, mask):
-        return torch.empty(self.handle.halo_words(mask), dtype=torch.int32, device=self.torch_device)
-
-    def halo_pack(self, side, mask, out):
-        self.handle.halo_pack(side, mask, out.data_ptr())
-
-    def halo_add(self, side, mask, src):
-        self.handle.halo_add(side, mask, src.data_ptr())
-
-    def extract_leavers(self, plane_starts):
-        counts = self.handle.extract_leavers(plane_starts, self._leavers.data_ptr(), self._leavers.shape[0])
-        return counts, self._leavers[: int(counts.sum())]
-
-    def find_leavers(self, plane_starts):
-        """Enqueues the classification; returns the device tensor the counts will appear in."""
-        if self._counts is None or self._counts.shape[0] != len(plane_starts) - 1:
-            self._counts = torch.zeros(len(plane_starts) - 1, dtype=torch.int64, device=self.torch_device)
-        self.handle.find_leavers(plane_starts, self._counts.data_ptr())
-        return self._counts
-
-    def refind_leavers(self, plane_starts):
-        """The classification again, on the slots the particles occupy now (a re-bin may have
-        moved them since find_leavers); the counts are the same and are not exported again."""
-        self.handle.find_leavers(plane_starts, 0)
-
-    def pack_leavers(self, counts):
-        self.handle.pack_leavers(counts, self._leavers.data_ptr(), self._leavers.shape[0])
-        return self._leavers[: int(np.asarray(counts).sum())]
-
-    def new_record_buffer(self, count):
-        return torch.empty((count, RECORD_WORDS), dtype=torch.float32, device=self.torch_device)
-
-    def grid_sums(self):
-        return self.handle.grid_sums()
-
-    def insert_arrivals(self, records):
-        self.handle.insert_arrivals(records.data_ptr(), records.shape[0])
-
-    def synchronize(self):
-        self.handle.synchronize()
-
-    def close(self):
-        self.handle.close()
-
-
-class SlabSimulation:
-    def __init__(self, grid, plane_starts, rank, world, max_particles=0, device=0,
-                 algorithm=_lib.ALGO_TILED, rebin_interval=1, dist=None, torch_device=None, backend=None):
-        self.grid = tuple(int(g) for g in grid)
-        self.plane_starts = [int(s) for s in plane_starts]
-        assert len(self.plane_starts) == world + 1 and self.plane_starts[0] == 0
-        assert self.plane_starts[-1] == self.grid[0]
-        self.rank, self.world, self.dist = rank, world, dist
-        self.x0 = self.plane_starts[rank]
-        self.nx = self.plane_starts[rank + 1] - self.x0
-        self.backend = backend if backend is not None else GpuSlabBackend(
-            self.grid, self.x0, self.nx, max_particles, device, algorithm, rebin_interval)
-        self.transport = _Transport(dist) if (dist is not None and world > 1) else None
-        # the tiled algorithm's two-pass p2g (mass, then summed momentum); other backends keep
-        # the reference's p2g1 / p2g2
-        fused = backend is None and algorithm == _lib.ALGO_TILED
-        self.p2g_kernels = ((_lib.KERNEL_P2G_MASS, _lib.KERNEL_P2G_MOMENTUM) if fused
-                            else (_lib.KERNEL_P2G1, _lib.KERNEL_P2G2))
-        # the device library's updateGrid keeps the float grid, so only the fixed-point grid is cleared
-        self.clear_kernel = _lib.KERNEL_CLEAR_FIXED_GRID if backend is None else _lib.KERNEL_CLEAR_GRID
-        # The library's tiled mass pass can skip the leavers itself and add the arrivals later, so it
-        # is enqueued before the host waits for the migration counts.
-        self.split_mass_pass = fused and world > 1
-        self.low = rank - 1 if rank > 0 else None
-        self.high = rank + 1 if rank < world - 1 else None
-        b = self.backend
-        masks = (_lib.COMP_MASS, _lib.COMP_MOMENTUM)
-        self._pending_counts = None
-        self._send = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
-        self._recv = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
-
-    # ---- set-up ----
-    def set_uniforms(self, **kw):
-        self.backend.set_uniforms(**kw)
-
-    def set_mode_uniforms(self, modes):
-        """The mode uniforms act per particle (keyed on the particle id, which migrates with
-        the particle), so every slab takes the same record."""
-        self.backend.set_mode_uniforms(modes)
-
-    def scatter_initial_particles(self, records, ids):
-        """Every rank brings any subset of the global particles; each record is routed to the
-        rank that owns floor(x), then uploaded there with its global id."""
-        records = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, _lib.PARTICLE_STRIDE)
-        ids = np.ascontiguousarray(ids, dtype=np.int32)
-        # uniforms.numParticles of the whole domain (mlsMpmSimulator.js:2513-2522): g2p's
-        # hide-percentage branch divides the particle id by it
-        total = records.shape[0]
-        if self.world > 1:
-            t = torch.tensor([total], dtype=torch.int64, device=self._comm_device())
-            self.dist.all_reduce(t)
-            total = int(t.item())
-        if total > 0 and hasattr(self.backend, "set_domain_particles"):
-            self.backend.set_domain_particles(total)
-        starts = np.asarray(self.plane_starts)
-        dest = np.clip(np.searchsorted(starts, np.floor(records[:, 0]).astype(np.int64), side="right") - 1,
-                       0, self.world - 1)
-        if self.world == 1:
-            self.backend.upload(records, ids)
-            return
-        order = np.argsort(dest, kind="stable")
-        counts = np.bincount(dest, minlength=self.world).astype(np.int64)
-        packed = np.empty((records.shape[0], _lib.PARTICLE_STRIDE + 1), dtype=np.float32)
-        packed[:, :_lib.PARTICLE_STRIDE] = records[order]
-        packed[:, _lib.PARTICLE_STRIDE] = ids[order].view(np.float32)
-        mine, offs = [], np.concatenate([[0], np.cumsum(counts)])
-        dev = self._comm_device()
-        matrix = self._all_gather_counts(counts, dev)
-        send_t = torch.from_numpy(packed).to(dev)
-        sends, recvs, inbox = [], [], []
-        for peer in range(self.world):
-            if peer == self.rank:
-                mine.append(packed[offs[peer]:offs[peer + 1]])
-                continue
-            if counts[peer]:
-                sends.append((send_t[offs[peer]:offs[peer + 1]], peer))
-            k = int(matrix[peer, self.rank])
-            if k:
-                buf = torch.empty((k, _lib.PARTICLE_STRIDE + 1), dtype=torch.float32, device=dev)
-                inbox.append(buf)
-                recvs.append((buf, peer))
-        self.transport.exchange(sends, recvs)
-        mine += [b.cpu().numpy() for b in inbox]
-        allrec = np.concatenate(mine, axis=0) if mine else np.zeros((0, _lib.PARTICLE_STRIDE + 1), np.float32)
-        self.backend.upload(np.ascontiguousarray(allrec[:, :_lib.PARTICLE_STRIDE]),
-                            np.ascontiguousarray(allrec[:, _lib.PARTICLE_STRIDE]).view(np.int32))
-
-    def _comm_device(self):
-        if self.dist is not None and self.dist.get_backend() == "nccl":
-            return self.backend.torch_device
-        return torch.device("cpu")
-
-    def _all_gather_counts(self, counts, dev):
-        """counts: numpy array or tensor of `world` int64.  Returns the world x world matrix
-        (row = sender) on the host."""
-        t = counts if torch.is_tensor(counts) else torch.from_numpy(np.asarray(counts, dtype=np.int64))
-        t = t.to(dev)
-        out = torch.empty(self.world * self.world, dtype=torch.int64, device=dev)
-        self.dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy().reshape(self.world, self.world)
-
-    # ---- the step ----
-    def _post_planes(self, mask):
-        """Both boundary planes of each side go to that side's neighbour, which adds them into
-        its matching pair: my LOW pair (planes x0-1, x0) is the low neighbour's HIGH pair.
-        Packs and starts the transfers; _add_planes finishes."""
-        if self.transport is None:
-            return None
-        b = self.backend
-        sends, recvs = [], []
-        if self.low is not None:
-            b.halo_pack(_lib.SIDE_LOW, mask, self._send["low", mask])
-            sends.append((self._send["low", mask], self.low))
-            recvs.append((self._recv["low", mask], self.low))
-        if self.high is not None:
-            b.halo_pack(_lib.SIDE_HIGH, mask, self._send["high", mask])
-            sends.append((self._send["high", mask], self.high))
-            recvs.append((self._recv["high", mask], self.high))
-        return self.transport.post(sends, recvs)
-
-    def _add_planes(self, mask, posted):
-        if self.transport is None:
-            return
-        b = self.backend
-        self.transport.complete(posted)
-        if self.low is not None:
-            b.halo_add(_lib.SIDE_LOW, mask, self._recv["low", mask])
-        if self.high is not None:
-            b.halo_add(_lib.SIDE_HIGH, mask, self._recv["high", mask])
-
-    def _exchange_planes(self, mask):
-        self._add_planes(mask, self._post_planes(mask))
-
-    def _begin_migration(self):
-        if self.transport is None:
-            return
-        self._pending_counts = self.backend.find_leavers(self.plane_starts)
-
-    def _finish_migration(self):
-        """Completes the migration begun after the last g2p (a no-op when none is pending)."""
-        counts_dev, self._pending_counts = self._pending_counts, None
-        if counts_dev is None:
-            return
-        b = self.backend
-        matrix = self._all_gather_counts(counts_dev, self._comm_device())
-        counts = matrix[self.rank]
-        packed = b.pack_leavers(counts)
-        if not matrix.any():
-            return
-        offs = np.concatenate([[0], np.cumsum(counts)])
-        sends, recvs, inbox = [], [], []
-        for peer in range(self.world):
-            if peer == self.rank:
-                continue
-            if counts[peer]:
-                sends.append((packed[int(offs[peer]):int(offs[peer + 1])], peer))
-            k = int(matrix[peer, self.rank])
-            if k:
-                buf = b.new_record_buffer(k)
-                inbox.append(buf)
-                recvs.append((buf, peer))
-        self.transport.exchange(sends, recvs)
-        for buf in inbox:
-            b.insert_arrivals(buf)
-
-    def step(self):
-        b = self.backend
-        p2g = self.p2g_kernels
-        b.run_kernel(self.clear_kernel)           # touches no particle: runs while the counts travel
-        if self.split_mass_pass:
-            # so does the mass pass of the particles that stay; the leavers are skipped on the
-            # device, the arrivals added once they are in
-            b.run_kernel(_lib.KERNEL_P2G_MASS_STAYERS)
-            if self._pending_counts is not None:
-                b.refind_leavers(self.plane_starts)
-            self._finish_migration()
-            b.run_kernel(_lib.KERNEL_P2G_MASS_ARRIVALS)
-        else:
-            self._finish_migration()
-            b.run_kernel(p2g[0])
-        self._exchange_planes(_lib.COMP_MASS)
-        b.run_kernel(p2g[1])
-        self._exchange_planes(_lib.COMP_MOMENTUM)
-        b.run_kernel(_lib.KERNEL_UPDATE_GRID)
-        b.run_kernel(_lib.KERNEL_G2P)
         self._begin_migration()
 
     def resident(self):
