@@ -49,7 +49,8 @@ def parse_args():
     ap.add_argument("--noise", type=float, default=0.0,
                     help="the noise uniform (conf.js default: 1.0); the noise field is computed either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=4,
+                    help="steps of the same workload the CPU oracle is timed on (about 12 s on 16 threads)")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo = rehearsal of the multi-rank path on fewer GPUs than ranks (host-staged transport)")
     ap.add_argument("--slab-yz", type=int, default=512, help="y and z extent of the multi-GPU domain")
