@@ -48,6 +48,9 @@ def parse_args():
                     help="HIP events on the kernels of every k-th timed step (1 = every step)")
     ap.add_argument("--noise", type=float, default=0.0,
                     help="the noise uniform (conf.js default: 1.0); the noise field is computed either way")
+    ap.add_argument("--rounds", type=int, default=1,
+                    help="N=1: time the K steps this many times back to back; the line reports the first as "
+                         "`value` and all of them, with median and minimum, under `rounds`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4,
                     help="steps of the same workload the CPU oracle is timed on (about 12 s on 16 threads)")
@@ -236,6 +239,14 @@ def run_single(args):
     h.synchronize()
     elapsed = time.perf_counter() - t0
     timings = h.timings()
+    # Optional repeat measurements in the same process (the simulation simply goes on): `value` stays
+    # the first timed region; the others are listed so that run-to-run spread can be judged.
+    extra_rounds = []
+    for r in range(1, args.rounds):
+        t1 = time.perf_counter()
+        advance(args.warmup + r * args.steps, args.steps)
+        h.synchronize()
+        extra_rounds.append(n * args.steps / (time.perf_counter() - t1))
     h.close()
     roof, per_kernel = roofline_of(timings, n, cells)
     workload_key = "%s_%d_%dx%dx%d" % (args.scene, n, grid[0], grid[1], grid[2])
@@ -264,6 +275,10 @@ def run_single(args):
         "rebin": {"performed": rebin.get("performed"), "timed_steps": rebin["launches"],
                   "avg_ms_per_timed_step": round(rebin["ms"] / rebin["launches"], 4) if rebin["launches"] else None},
     }
+    if extra_rounds:
+        values = [line["value"]] + extra_rounds
+        line["rounds"] = {"values": [round(v, 1) for v in values], "median": round(float(np.median(values)), 1),
+                          "min": round(min(values), 1)}
     if not args.no_cpu_baseline and args.mode == "chaos":
         line["cpu_baseline"] = cpu_baseline(rec, n, grid, uniforms, args.cpu_steps)
     return line
