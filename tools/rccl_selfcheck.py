@@ -56,6 +56,16 @@ def main():
         torch.cuda.synchronize()
         report["p2p_self_int32"] = bool((a == b).all().item())
         report["p2p_self_rows"] = bool((rec[100:600] == rec_in[100:600]).all().item())
+        # posted, then compute enqueued on the current stream, then completed: what the slab step
+        # does with a halo exchange and the interior part of a stage
+        c = torch.zeros_like(a)
+        posted = tr.post([(a, 0)], [(c, 0)])
+        m = torch.rand((2048, 2048), device=dev)
+        for _ in range(8):
+            m = (m @ m).clamp_(0.0, 1.0)
+        tr.complete(posted)
+        torch.cuda.synchronize()
+        report["p2p_self_overlapped"] = bool((a == c).all().item()) and bool(torch.isfinite(m).all().item())
     except Exception as exc:                       # self send/recv is optional in the library
         report["p2p_self"] = "not supported here: %s" % (str(exc).splitlines()[0],)
 
