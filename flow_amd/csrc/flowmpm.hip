@@ -894,6 +894,9 @@ int flowmpm_get_timings(flowmpm_sim *s, flowmpm_timings *out)
         HIP_TRY(s, hipMemcpyAsync(&ctl, s->tiled.ctl, sizeof ctl, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(s, hipStreamSynchronize(s->stream));
         out->launches[FLOWMPM_TIMING_REBINS_DONE] = ctl.rebins;
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->cfg.device) == hipSuccess && khz > 0)
+            out->ms[FLOWMPM_TIMING_REBINS_DONE] = (double)ctl.busy_ticks / (double)khz;
     }
     return FLOWMPM_OK;
 }
@@ -905,7 +908,7 @@ int flowmpm_reset_timings(flowmpm_sim *s)
     if (rc) return rc;
     s->timings = flowmpm_timings{};
     if (is_tiled(s))
-        HIP_TRY(s, hipMemsetAsync(&s->tiled.ctl->rebins, 0, sizeof(int), s->stream));
+        HIP_TRY(s, hipMemsetAsync(&s->tiled.ctl->rebins, 0, sizeof(int) + sizeof(unsigned long long), s->stream));
     return FLOWMPM_OK;
 }
 

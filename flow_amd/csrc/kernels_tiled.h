@@ -83,7 +83,10 @@ struct RebinCtl {
     int cum_drift;   // sum over those stages of the particles left outside their arena
     int binned;      // particles [0, binned) are covered by the work items
     int rebins;      // re-bins performed since the counter was last cleared
-    int pad[2];
+    // Device time those re-bins took, in ticks of the constant-rate wall clock (from the first
+    // workgroup of the first launch to the commit in the second), and the start of the one in flight.
+    unsigned long long busy_ticks;
+    unsigned long long t_start;      // ~0 when no re-bin is in flight
 };
 
 struct TiledState {
@@ -235,6 +238,7 @@ bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict
                       RebinCtl *ctl, int interval, int force, int divisor)
 {
     if (!rebin_due(ctl, n, interval, force, divisor)) return;
+    if (threadIdx.x == 0) atomicMin(&ctl->t_start, (unsigned long long)wall_clock64());
     const Store st = ss.pick();
     const int lane = threadIdx.x & 63;
     // Each workgroup takes one contiguous run of particles: the store is nearly sorted, so a run
@@ -283,6 +287,8 @@ bin_scatter_kernel(StoreSel ss, int n, const int *__restrict__ key, const int *_
         ctl->cum_drift = 0;
         ctl->binned = n;
         ctl->rebins += 1;
+        ctl->busy_ticks += (unsigned long long)wall_clock64() - ctl->t_start;
+        ctl->t_start = ~0ULL;
     }
 }
 
@@ -1118,6 +1124,7 @@ inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStr
     T.stage_parity = 0;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.ctl), sizeof(RebinCtl)), "hipMalloc rebin control")) return 1;
     if (chk(e = hipMemsetAsync(T.ctl, 0, sizeof(RebinCtl), stream), "memset rebin control")) return 1;
+    if (chk(e = hipMemsetAsync(&T.ctl->t_start, 0xFF, sizeof(unsigned long long), stream), "memset rebin clock")) return 1;
     T.valid = false;
     T.checked = false;
     return 0;

@@ -171,6 +171,7 @@ class Handle:
         names = list(_lib.KERNEL_NAMES) + ["rebin"]
         out = {names[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(len(names))}
         out["rebin"]["performed"] = t.launches[_lib.TIMING_REBINS_DONE]
+        out["rebin"]["performed_ms"] = t.ms[_lib.TIMING_REBINS_DONE]      # device clock, every step
         return out
 
     # ---- slab decomposition ----

@@ -80,7 +80,9 @@ extern "C" {
 /* Timing slots reported by flowmpm_get_timings: the five kernels, then the
  * particle re-binning pass of the tiled algorithm (no reference counterpart). */
 #define FLOWMPM_TIMING_REBIN        5   /* the start-of-step re-binning sequence (runs every step; most return at once) */
-#define FLOWMPM_TIMING_REBINS_DONE  6   /* launches[] only: re-bins the device actually performed */
+#define FLOWMPM_TIMING_REBINS_DONE  6   /* the re-bins the device actually performed: launches[] their number,
+                                          ms[] the device time they took (device wall clock, every step,
+                                          whatever the profiling stride) */
 #define FLOWMPM_TIMING_SLOTS        8
 
 /* How the particle-to-grid scatter is organised. */
