@@ -331,6 +331,7 @@ def run_distributed(args):
     sim.synchronize()
     handle = getattr(sim.backend, "handle", None)
     n_start = sim.resident()
+    migrated_at_start = sim.migrated_out
     if handle is not None:
         handle.set_profiling(args.timing_stride)
         handle.reset_timings()
@@ -354,13 +355,14 @@ def run_distributed(args):
     if timings is not None:
         busy = sum(t["ms"] / t["launches"] for name, t in timings.items()
                    if name in BYTES and t["launches"])
-    busy_t = torch.tensor([busy], dtype=torch.float64, device=comm_dev)
+    rebins = timings["rebin"]["performed"] if timings is not None else 0
+    busy_t = torch.tensor([busy, rebins, sim.migrated_out - migrated_at_start], dtype=torch.float64, device=comm_dev)
     busy_all = [torch.zeros_like(busy_t) for _ in range(world)]
     dist.all_gather(busy_all, busy_t)
     line = None
     if rank == 0:
         per_rank = [int(g.item()) for g in gathered]
-        per_rank_busy = [round(float(b.item()), 4) for b in busy_all]
+        per_rank_busy = [round(float(b[0].item()), 4) for b in busy_all]
         # rank 0's own launches (HIP events on its stream, sampled like the single-GPU run),
         # against the algorithmic bytes of the particles and cells that rank holds
         roof, per_kernel = None, None
@@ -381,6 +383,8 @@ def run_distributed(args):
                        "rebin_interval": args.rebin_interval, "parallelism": "slab%d" % world,
                        "plane_starts": [int(s) for s in starts], "resident_per_rank_end": per_rank,
                        "kernel_ms_per_step_per_rank": per_rank_busy,
+                       "rebins_per_rank": [int(b[1].item()) for b in busy_all],
+                       "particles_sent_away_per_step_per_rank": [round(float(b[2].item()) / args.steps, 1) for b in busy_all],
                        "kernel_time_imbalance_max_over_mean":
                            round(max(per_rank_busy) / (sum(per_rank_busy) / world), 4) if sum(per_rank_busy) else None},
             "roofline": roof, "kernels": per_kernel, "cpu_baseline": None,

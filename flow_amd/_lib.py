@@ -14,7 +14,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_CAPACITY = 0, 1, 2, 3, 4
 PARTICLE_STRIDE = 28
 KERNEL_CLEAR_GRID, KERNEL_P2G1, KERNEL_P2G2, KERNEL_UPDATE_GRID, KERNEL_G2P = range(5)
 KERNEL_NAMES = ("clearGrid", "p2g1", "p2g2", "updateGrid", "g2p")
-TIMING_REBIN, TIMING_REBINS_DONE, TIMING_SLOTS = 5, 6, 8
+TIMING_REBIN, TIMING_REBINS_DONE, TIMING_STRAGGLERS, TIMING_SLOTS = 5, 6, 7, 8
 ALGO_SCATTER, ALGO_TILED, ALGO_TILED_UNFUSED = 0, 1, 2
 KERNEL_P2G_MASS, KERNEL_P2G_MOMENTUM = 16, 17
 KERNEL_CLEAR_FIXED_GRID = 18     # clearGrid without the float grid (updateGrid then keeps it)

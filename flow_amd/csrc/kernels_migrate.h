@@ -26,23 +26,68 @@ __device__ __forceinline__ bool is_leaver(float px, int x0, int nx)
     return ix < x0 || ix >= x0 + nx;
 }
 
-// counters[0..kMaxRanks): leavers per destination; counters[kMaxRanks]: total.
+// counters[0..kMaxRanks): leavers per destination; [kMaxRanks]: total; [kMaxRanks + 1], [+ 2]: holes and
+// movers of the compaction; [kRedoWord]: whether the classification in flight runs; [kEpochWord]: the
+// store's binning epoch the leaver list belongs to.
+constexpr int kRedoWord = kMaxRanks + 3, kEpochWord = kMaxRanks + 4, kCounterWords = kMaxRanks + 5;
+
+// One workgroup, before find_leavers_kernel.  only_if_moved: the list of the last classification is
+// kept (and the classification skipped) when the store has not been re-binned since -- `epoch` counts
+// the re-bins and is null for a store that never is.
+__global__ void __launch_bounds__(128)
+find_prologue_kernel(int *counters, const int *epoch, int only_if_moved)
+{
+    const int now = epoch ? *epoch : 0;
+    const bool redo = !only_if_moved || !epoch || counters[kEpochWord] != now;
+    __syncthreads();                                   // every thread has read the old epoch word
+    if (redo)
+        for (int i = threadIdx.x; i < kMaxRanks + 3; i += blockDim.x) counters[i] = 0;
+    if (threadIdx.x == 0) { counters[kRedoWord] = redo ? 1 : 0; counters[kEpochWord] = now; }
+}
+
+// Leavers are few and sit next to each other in the store (they come from the boundary tiles), so the
+// lanes of a wave share their atomics: one on the total, one per destination present in the wave.
 __global__ void __launch_bounds__(256)
 find_leavers_kernel(StoreSel ss, long long n, int x0, int nx, RankTable rt, int *counters,
                     int *list_slot, int *list_dest, int *list_k, long long list_cap)
 {
+    if (counters[kRedoWord] == 0) return;
     const Store st = ss.pick();
-    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    float px = st.slot(kPosX)[j];
-    if (!is_leaver(px, x0, nx)) return;
-    int ix = f32_to_i32(px);
-    int dest = 0;
-    for (int r = 0; r < rt.n; r++)
-        if (ix >= rt.starts[r]) dest = r;
-    int k = atomicAdd(&counters[dest], 1);
-    int e = atomicAdd(&counters[kMaxRanks], 1);
-    if (e < list_cap) { list_slot[e] = (int)j; list_dest[e] = dest; list_k[e] = k; }
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    // every lane of a wave runs the same rounds (the ballots and shuffles need the whole wave)
+    for (long long j0 = (long long)blockIdx.x * blockDim.x; j0 < n; j0 += (long long)gridDim.x * blockDim.x) {
+        const long long j = j0 + threadIdx.x;
+        bool leaver = false;
+        int dest = 0;
+        if (j < n) {
+            const float px = st.slot(kPosX)[j];
+            leaver = is_leaver(px, x0, nx);
+            if (leaver) {
+                const int ix = f32_to_i32(px);
+                for (int r = 0; r < rt.n; r++)
+                    if (ix >= rt.starts[r]) dest = r;
+            }
+        }
+        const unsigned long long all = __ballot(leaver);
+        if (all == 0) continue;                            // the whole wave
+        const int first = __ffsll((long long)all) - 1;
+        int e = 0;
+        if (lane == first) e = atomicAdd(&counters[kMaxRanks], __popcll(all));
+        e = __shfl(e, first) + __popcll(all & below);
+        int k = 0;
+        for (unsigned long long rest = all; rest != 0;) {  // uniform: one round per destination present
+            const int leader = __ffsll((long long)rest) - 1;
+            const int d = __shfl(dest, leader);
+            const unsigned long long same = __ballot(leaver && dest == d);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&counters[d], __popcll(same));
+            base = __shfl(base, leader);
+            if (leaver && dest == d) k = base + __popcll(same & below);
+            rest &= ~same;
+        }
+        if (leaver && e < list_cap) { list_slot[e] = (int)j; list_dest[e] = dest; list_k[e] = k; }
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -108,7 +153,7 @@ __global__ void export_counts_kernel(const int *__restrict__ counters, int n_ran
 }
 
 struct MigrationScratch {
-    int *counters = nullptr;      // kMaxRanks + 3 device words
+    int *counters = nullptr;      // kCounterWords device words
     int *lists = nullptr;         // 5 device arrays of list_cap ints
     long long list_cap = 0;
     RankTable table{};            // of the classification in flight
@@ -119,8 +164,12 @@ inline int migration_reserve(MigrationScratch &M, long long want, std::string *m
 {
     hipError_t e;
     if (!M.counters) {
-        if ((e = hipMalloc(reinterpret_cast<void **>(&M.counters), (kMaxRanks + 3) * sizeof(int))) != hipSuccess) {
+        if ((e = hipMalloc(reinterpret_cast<void **>(&M.counters), kCounterWords * sizeof(int))) != hipSuccess) {
             *msg = std::string("hipMalloc counters: ") + hipGetErrorString(e);
+            return 1;
+        }
+        if ((e = hipMemset(M.counters, 0, kCounterWords * sizeof(int))) != hipSuccess) {
+            *msg = std::string("hipMemset counters: ") + hipGetErrorString(e);
             return 1;
         }
     }
@@ -137,24 +186,35 @@ inline int migration_reserve(MigrationScratch &M, long long want, std::string *m
     return 0;
 }
 
+// Workgroups of find_leavers_kernel: enough to fill the chip, each with several rounds of 256 particles.
+inline unsigned find_blocks(long long n) { return (unsigned)std::min<long long>((n + 255) / 256, 4096); }
+
 // Enqueues the classification of the n resident particles: leaver counts per destination
 // rank and the leaver list.  Nothing is read back here.  dev_counts (may be null) receives
-// the n_ranks counts as 64-bit words.  Returns 0 ok, 1 HIP failure.
+// the n_ranks counts as 64-bit words.  only_if_moved: a classification of the same particles is
+// in flight and is repeated only if the store has been re-binned since (`epoch`, a device word that
+// counts the re-bins, null for a store without binning); the device decides.
+// Returns 0 ok, 1 HIP failure, 3 call order.
 inline int find_leavers(MigrationScratch &M, StoreSel st, long long n, int x0, int nx, const int32_t *plane_starts,
-                        int n_ranks, long long *dev_counts, hipStream_t stream, std::string *msg)
+                        int n_ranks, long long *dev_counts, const int *epoch, bool only_if_moved,
+                        hipStream_t stream, std::string *msg)
 {
+    if (only_if_moved && (M.classified != n || M.table.n != n_ranks)) {
+        *msg = "no classification of these particles is in flight";
+        return 3;
+    }
     if (migration_reserve(M, std::max<long long>(M.list_cap, 4096), msg)) return 1;
     M.table = RankTable{};
     M.table.n = n_ranks;
     for (int r = 0; r <= n_ranks; r++) M.table.starts[r] = plane_starts[r];
-    hipError_t e = hipMemsetAsync(M.counters, 0, (kMaxRanks + 3) * sizeof(int), stream);
-    if (e != hipSuccess) { *msg = std::string("memset counters: ") + hipGetErrorString(e); return 1; }
+    hipLaunchKernelGGL(find_prologue_kernel, dim3(1), dim3(128), 0, stream, M.counters, epoch, only_if_moved ? 1 : 0);
     const long long cap = M.list_cap;
     if (n > 0)
-        hipLaunchKernelGGL(find_leavers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st, n, x0, nx,
+        hipLaunchKernelGGL(find_leavers_kernel, dim3(find_blocks(n)), dim3(256), 0, stream, st, n, x0, nx,
                            M.table, M.counters, M.lists, M.lists + cap, M.lists + 2 * cap, cap);
     if (dev_counts)
         hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kMaxRanks), 0, stream, M.counters, n_ranks, dev_counts);
+    hipError_t e;
     if ((e = hipGetLastError()) != hipSuccess) { *msg = std::string("find_leavers: ") + hipGetErrorString(e); return 1; }
     M.classified = n;
     return 0;
@@ -179,12 +239,10 @@ inline int pack_leavers(MigrationScratch &M, StoreSel st, long long n, int x0, i
     if (total > M.list_cap) {
         // the list overflowed: grow it and classify again (positions have not changed since)
         if (migration_reserve(M, total, msg)) return 1;
-        if ((e = hipMemsetAsync(M.counters, 0, (kMaxRanks + 3) * sizeof(int), stream)) != hipSuccess) {
-            *msg = std::string("memset counters: ") + hipGetErrorString(e);
-            return 1;
-        }
+        hipLaunchKernelGGL(find_prologue_kernel, dim3(1), dim3(128), 0, stream, M.counters,
+                           static_cast<const int *>(nullptr), 0);
         const long long cap = M.list_cap;
-        hipLaunchKernelGGL(find_leavers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st, n, x0, nx,
+        hipLaunchKernelGGL(find_leavers_kernel, dim3(find_blocks(n)), dim3(256), 0, stream, st, n, x0, nx,
                            M.table, M.counters, M.lists, M.lists + cap, M.lists + 2 * cap, cap);
     }
     const long long cap = M.list_cap;
@@ -213,7 +271,7 @@ inline int extract_leavers(MigrationScratch &M, StoreSel st, long long n, int x0
     for (int r = 0; r < n_ranks; r++) counts[r] = 0;
     *new_resident = n;
     if (n == 0) return 0;
-    if (find_leavers(M, st, n, x0, nx, plane_starts, n_ranks, nullptr, stream, msg)) return 1;
+    if (find_leavers(M, st, n, x0, nx, plane_starts, n_ranks, nullptr, nullptr, false, stream, msg)) return 1;
     int host_counters[kMaxRanks + 3];
     hipError_t e = hipMemcpyAsync(host_counters, M.counters, sizeof host_counters, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);

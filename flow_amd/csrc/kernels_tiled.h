@@ -86,7 +86,10 @@ struct RebinCtl {
     // Device time those re-bins took, in ticks of the constant-rate wall clock (from the first
     // workgroup of the first launch to the commit in the second), and the start of the one in flight.
     unsigned long long busy_ticks;
+    unsigned long long stragglers;   // particles the g2p stages since then handed to the follow-up kernel
     unsigned long long t_start;      // ~0 when no re-bin is in flight
+    int epoch;       // re-bins performed since the store was created (never cleared): slot indices
+    int unused;      // taken under one epoch are stale under the next
 };
 
 struct TiledState {
@@ -104,6 +107,9 @@ struct TiledState {
     int *straggler_counts = nullptr;   // two device scalars used by alternate stages
     int *straggler_list = nullptr;
     int stage_parity = 0;        // which of the two the next stage counts into
+    // The counter (0 / 1) under which the last momentum pass or p2g2 listed its stragglers, while the
+    // particles are still the ones it saw, in the same slots; -1 otherwise.  g2p then reuses the list.
+    int listed = -1;
 };
 
 // Two floats that one packed instruction (v_pk_mul_f32, v_pk_add_f32) operates on.
@@ -287,6 +293,7 @@ bin_scatter_kernel(StoreSel ss, int n, const int *__restrict__ key, const int *_
         ctl->cum_drift = 0;
         ctl->binned = n;
         ctl->rebins += 1;
+        ctl->epoch += 1;
         ctl->busy_ticks += (unsigned long long)wall_clock64() - ctl->t_start;
         ctl->t_start = ~0ULL;
     }
@@ -315,9 +322,36 @@ __device__ __forceinline__ long long arena_cell_to_grid(int a, const Arena &A, c
     return local_cell(A.ox + ax, A.oy + ay, A.oz + az, P);
 }
 
-__device__ __forceinline__ void add_straggler(const Stragglers &sg, int j)
+// A workgroup collects its stragglers in LDS and appends them to the list with ONE atomic on the
+// shared counter (an atomic per straggler, all on that one word and each waiting for its return
+// value, cost the tiled kernels 5-6 ns per straggler); what does not fit goes there directly.
+constexpr int kStragglerBuf = 126;
+struct StragglerBuf { int n, base, slot[kStragglerBuf]; };
+
+__device__ __forceinline__ void add_straggler_direct(const Stragglers &sg, int j)
 {
     sg.list[atomicAdd(sg.count, 1)] = j;
+}
+
+// before the first barrier of the kernel
+__device__ __forceinline__ void straggler_buf_init(StragglerBuf &b) { if (threadIdx.x == 0) b.n = 0; }
+
+__device__ __forceinline__ void add_straggler(const Stragglers &sg, StragglerBuf &b, int j)
+{
+    const int k = atomicAdd(&b.n, 1);
+    if (k < kStragglerBuf) b.slot[k] = j;
+    else sg.list[atomicAdd(sg.count, 1)] = j;
+}
+
+// after the particle loop, by every thread of the workgroup; starts with a barrier
+__device__ __forceinline__ void straggler_buf_flush(const Stragglers &sg, StragglerBuf &b)
+{
+    __syncthreads();
+    const int n = min(b.n, kStragglerBuf);
+    if (n == 0) return;                                 // uniform
+    if (threadIdx.x == 0) b.base = atomicAdd(sg.count, n);
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += blockDim.x) sg.list[b.base + k] = b.slot[k];
 }
 
 // Adds every non-zero word of an LDS arena component to the global grid.  A wave
@@ -341,6 +375,14 @@ __device__ __forceinline__ unsigned stencil_tile_bits(int bx, int by, int bz)
     return yz * spread(axis(bx, kTX), 9);
 }
 
+// Sets bits in a tile's word.  Many particles mark the same few tiles, and atomics on one word are
+// served one after the other, so the word is read first: within a kernel bits are only ever set, and a
+// bit that reads as set needs nothing.
+__device__ __forceinline__ void set_dirty(int *word, int bits)
+{
+    if ((*word & bits) != bits) atomicOr(word, bits);
+}
+
 // `touched` holds, per thread, the stencil_tile_bits of every particle it scattered into the
 // arena of `tile`.  Sets g.dirty_bits on those tiles.  All threads of the workgroup call it.
 __device__ __forceinline__ void mark_dirty_tiles(unsigned touched, int tile, TileDims td, const FixedGrid &g)
@@ -358,7 +400,7 @@ __device__ __forceinline__ void mark_dirty_tiles(unsigned touched, int tile, Til
         const int k = threadIdx.x;
         const int nx = tx + k / 9 - 1, ny = ty + (k / 3) % 3 - 1, nz = tz + k % 3 - 1;
         // a cell that exists lies in a tile that exists
-        atomicOr(&g.dirty[(nx * td.tiles_y + ny) * td.tiles_z + nz], g.dirty_bits);
+        set_dirty(&g.dirty[(nx * td.tiles_y + ny) * td.tiles_z + nz], g.dirty_bits);
     }
 }
 
@@ -372,7 +414,7 @@ __device__ __forceinline__ void mark_dirty_stencil(const Stencil &s, TileDims td
         const int lx = cx - P.x_off;
         if ((unsigned)lx >= (unsigned)P.local_nx || (unsigned)cy >= (unsigned)P.gy || (unsigned)cz >= (unsigned)P.gz)
             continue;
-        atomicOr(&g.dirty[((lx / kTX) * td.tiles_y + cy / kTY) * td.tiles_z + cz / kTZ], g.dirty_bits);
+        set_dirty(&g.dirty[((lx / kTX) * td.tiles_y + cy / kTY) * td.tiles_z + cz / kTZ], g.dirty_bits);
     }
 }
 
@@ -487,6 +529,8 @@ p2g1_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     if (!take_item(w, &item)) return;
     const Stragglers sg = w.sg;
     __shared__ int lds[4 * kArenaPad];
+    __shared__ StragglerBuf sb;
+    straggler_buf_init(sb);
     const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < 4 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     __syncthreads();
@@ -504,8 +548,9 @@ p2g1_tiled_kernel(TiledWork w, FixedGrid g, Params P)
             p2g1_particle<true>(s, vx, vy, vz, C, lds, abase, g, P);
             touched |= stencil_tile_bits(s.cx - A.ox, s.cy - A.oy, s.cz - A.oz);
         } else
-            add_straggler(sg, j);
+            add_straggler(sg, sb, j);
     }
+    straggler_buf_flush(sg, sb);
     __syncthreads();
     flush_arena<4>(lds, A, P, g);
     mark_dirty_tiles(touched, item.x, w.td, g);
@@ -579,6 +624,8 @@ p2g2_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     const Stragglers sg = w.sg;
     __shared__ int lds[3 * kArenaPad];
     __shared__ float mass_f[kArenaCells];      // decodeFixedPoint(cell.mass), once per arena cell
+    __shared__ StragglerBuf sb;
+    straggler_buf_init(sb);
     const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
@@ -599,8 +646,9 @@ p2g2_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         if (stencil_in_arena(s, A, &abase))
             p2g2_particle<true>(s, C, dens + j, lds, mass_f, abase, g, P);
         else
-            add_straggler(sg, j);
+            add_straggler(sg, sb, j);
     }
+    straggler_buf_flush(sg, sb);
     __syncthreads();
     flush_arena<3>(lds, A, P, g);
 }
@@ -650,6 +698,8 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     if (!take_item(w, &item)) return;
     const Stragglers sg = w.sg;
     __shared__ int lds[kArenaCells];
+    __shared__ StragglerBuf sb;
+    straggler_buf_init(sb);
     const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < kArenaCells; i += kTiledThreads) lds[i] = 0;
     __syncthreads();
@@ -664,8 +714,9 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
             p2g_mass_particle<true>(s, lds, abase, g, P);
             touched |= stencil_tile_bits(s.cx - A.ox, s.cy - A.oy, s.cz - A.oz);
         } else
-            add_straggler(sg, j);
+            add_straggler(sg, sb, j);
     }
+    straggler_buf_flush(sg, sb);
     __syncthreads();
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
         int v = lds[a];
@@ -751,6 +802,8 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     const Stragglers sg = w.sg;
     __shared__ int lds[3 * kArenaPad];
     __shared__ float mass_f[kArenaCells];
+    __shared__ StragglerBuf sb;
+    straggler_buf_init(sb);
     const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
@@ -781,7 +834,7 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         if (stencil_in_arena(s, A, &abase))
             p2g_momentum_particle<true>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + j, lds, mass_f, abase, g, P);
         else
-            add_straggler(sg, j);
+            add_straggler(sg, sb, j);
 #if FLOWMPM_PREFETCH_P2G
 #pragma unroll
         for (int k = 0; k < 15; k++) in[k] = nx[k];
@@ -793,6 +846,7 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 #endif
         j = jn;
     }
+    straggler_buf_flush(sg, sb);
     __syncthreads();
     flush_arena<3>(lds, A, P, g);
 }
@@ -858,7 +912,10 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
     v.x = vxy.x; v.y = vxy.y; v.z = vz;
 }
 
-template <bool MODES>
+// LISTED: the momentum pass (or p2g2) of this step ran on the same particles in the same slots and
+// left the list of those whose stencil is outside their arena -- g2p applies the same test to the
+// same positions, so it skips them without listing them again.
+template <bool MODES, bool LISTED>
 __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_G2P_WAVES)
 g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
                  const ModeParams *__restrict__ M)
@@ -928,8 +985,8 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
                       bz = f32_to_i32(o.pz) - 1 - A.oz;
             drifted += !((unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
                          (unsigned)bz <= (unsigned)(kAZ - 3));
-        } else {
-            add_straggler(sg, j);
+        } else if (!LISTED) {
+            add_straggler_direct(sg, j);
         }
 #if FLOWMPM_PREFETCH_G2P
         in = nx;
@@ -949,7 +1006,7 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
 // One thread per particle the tiled kernel did not handle -- those it listed, and the live
 // particles past the binned range (arrivals from other slabs since the last re-bin) -- with
 // contributions straight to / from the global grids (the reference's own access pattern).
-// PASS: 0 p2g1, 1 p2g2, 2 mass pass, 3 momentum pass.
+// PASS: 0 p2g1, 1 p2g2.
 __device__ __forceinline__ int straggler_total(const TiledWork &w, int *count, int *tail_begin)
 {
     *count = *w.sg.count;
@@ -971,14 +1028,88 @@ straggler_p2g_kernel(TiledWork w, FixedGrid g, Params P)
 #pragma unroll
         for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
         Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
-        if (PASS == 2 && (s.cx + 1 < w.keep_lo || s.cx + 1 >= w.keep_hi)) continue;
         mark_dirty_stencil(s, w.td, P, g);
         if (PASS == 0) p2g1_particle<false>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, nullptr, 0, g, P);
         if (PASS == 1) p2g2_particle<false>(s, in + kC00, st.slot(kDensity) + j, nullptr, nullptr, 0, g, P);
-        if (PASS == 2) p2g_mass_particle<false>(s, nullptr, 0, g, P);
-        if (PASS == 3)
-            p2g_momentum_particle<false>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, st.slot(kDensity) + j,
-                                         nullptr, nullptr, 0, g, P);
+    }
+}
+
+__device__ __forceinline__ float pick3(const float a[3], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
+
+// The stragglers of the two passes of the step (MOMENTUM false: mass pass, true: momentum pass),
+// 32 lanes to a particle: lane c < 27 takes stencil cell c = (gx * 3 + gy) * 3 + gz -- its mass
+// word, its three momentum words -- so a particle's 27 + 81 atomics and 27 mass loads are issued
+// side by side instead of one after the other, and the three cells of a z run fall into adjacent
+// records.  The density is the one quantity that couples the cells: it is summed in the reference's
+// order (SIM:353-364), every lane adding the 27 products one after the other.
+template <bool MOMENTUM>
+__global__ void __launch_bounds__(256)
+straggler_p2g_team_kernel(TiledWork w, FixedGrid g, Params P)
+{
+    const Store st = w.store.pick();
+    int count, tail_begin;
+    const int total = straggler_total(w, &count, &tail_begin);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *w.sg.next_count = 0;
+    const int c = threadIdx.x & 31;                    // stencil cell of this lane (27..31: none)
+    const int team_lane0 = threadIdx.x & 32;           // first lane of this team within the wave
+    const int gx = c / 9, gy = (c / 3) % 3, gz = c % 3;
+    const int teams = gridDim.x * (blockDim.x >> 5);
+    // every lane of a wave runs the same number of rounds (the shuffles below need the whole team)
+    for (int i0 = blockIdx.x * (blockDim.x >> 5) + ((threadIdx.x >> 6) << 1); i0 < total; i0 += teams) {
+        const int i = i0 + ((threadIdx.x >> 5) & 1);
+        const bool live = i < total;
+        const int j = !live ? 0 : (i < count ? w.sg.list[i] : tail_begin + (i - count));
+        float px = 2.0f, py = 2.0f, pz = 2.0f;
+        if (live) { px = st.slot(kPosX)[j]; py = st.slot(kPosY)[j]; pz = st.slot(kPosZ)[j]; }
+        const Stencil s = make_stencil(px, py, pz);
+        const bool mine = live && c < 27 &&
+                          !(!MOMENTUM && (s.cx + 1 < w.keep_lo || s.cx + 1 >= w.keep_hi));
+        const float weight = (pick3(s.wx, gx) * pick3(s.wy, gy)) * pick3(s.wz, gz);
+        const long long cell = mine ? local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P) : -1;
+        if (mine && c < 8 && g.dirty) {                // mark_dirty_stencil, one corner per lane
+            const int cx = s.cx + (c & 4 ? 2 : 0), cy = s.cy + (c & 2 ? 2 : 0), cz = s.cz + (c & 1 ? 2 : 0);
+            const int lx = cx - P.x_off;
+            if ((unsigned)lx < (unsigned)P.local_nx && (unsigned)cy < (unsigned)P.gy && (unsigned)cz < (unsigned)P.gz)
+                set_dirty(&g.dirty[((lx / kTX) * w.td.tiles_y + cy / kTY) * w.td.tiles_z + cz / kTZ], g.dirty_bits);
+        }
+        if (!MOMENTUM) {
+            if (cell >= 0) atomicAdd(g.mass + cell, encode_fixed(weight));
+            continue;
+        }
+        float vx = 0.0f, vy = 0.0f, vz = 0.0f, C[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) C[k] = 0.0f;
+        if (live) {
+            vx = st.slot(kVelX)[j]; vy = st.slot(kVelY)[j]; vz = st.slot(kVelZ)[j];
+#pragma unroll
+            for (int k = 0; k < 9; k++) C[k] = st.slot(kC00 + k)[j];
+        }
+        const float term = decode_fixed(cell >= 0 ? g.mass[cell] : 0) * weight;
+        float density = 0.0f;
+        for (int k = 0; k < 27; k++) density = density + __shfl(term, team_lane0 + k);
+        if (live && c == 0) {
+            float *dens_slot = st.slot(kDensity) + j;
+            *dens_slot = *dens_slot * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
+        }
+        const Eq16 e = p2g2_stress(density, C, P);
+        const float dx = pick3(s.dx, gx), dy = pick3(s.dy, gy), dz = pick3(s.dz, gz);
+        // as in p2g_momentum_particle
+        const float qx = (C[0] * dx + C[3] * dy) + C[6] * dz;
+        const float qy = (C[1] * dx + C[4] * dy) + C[7] * dz;
+        const float qz = (C[2] * dx + C[5] * dy) + C[8] * dz;
+        int ex = encode_fixed(weight * (vx + qx));
+        int ey = encode_fixed(weight * (vy + qy));
+        int ez = encode_fixed(weight * (vz + qz));
+        const float a00 = e.m00 * weight, a11 = e.m11 * weight, a22 = e.m22 * weight;
+        const float a01 = e.m01 * weight, a02 = e.m02 * weight, a12 = e.m12 * weight;
+        ex = add_wrap(ex, encode_fixed((a00 * dx + a01 * dy) + a02 * dz));
+        ey = add_wrap(ey, encode_fixed((a01 * dx + a11 * dy) + a12 * dz));
+        ez = add_wrap(ez, encode_fixed((a02 * dx + a12 * dy) + a22 * dz));
+        if (cell >= 0) {
+            atomicAdd(g.cell + 4 * cell + 0, ex);
+            atomicAdd(g.cell + 4 * cell + 1, ey);
+            atomicAdd(g.cell + 4 * cell + 2, ez);
+        }
     }
 }
 
@@ -995,6 +1126,7 @@ straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
         // bookkeeping of the step that ends here: every particle on this path counts as outside
         if (total) atomicAdd(&w.ctl->cum_drift, total);
         w.ctl->age += 1;
+        w.ctl->stragglers += (unsigned long long)total;
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int j = i < count ? w.sg.list[i] : tail_begin + (i - count);
@@ -1156,6 +1288,7 @@ inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P
 {
     const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, kBinBlocks);
     const int force = T.valid ? 0 : 1;
+    T.listed = -1;
     hipExtLaunchKernelGGL(bin_count_scan_kernel, dim3(blocks), dim3(256), 0, stream, ev_start, nullptr, 0, ss, (int)n,
                           P, tile_dims(T), T.key, T.rank, T.tile_count, T.n_tiles, T.tile_start, T.items, T.n_items,
                           T.item_cap, T.ctl, interval, force, divisor);
@@ -1214,6 +1347,7 @@ inline int launch_p2g1_tiled(TiledState &T, StoreSel st, long long n, FixedGrid 
 inline int launch_p2g2_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream,
                              hipEvent_t ev_start, hipEvent_t ev_stop)
 {
+    T.listed = T.stage_parity;
     FLOWMPM_TILED_STAGE(p2g2_tiled_kernel, straggler_p2g_kernel<1>, g);
 }
 
@@ -1227,7 +1361,7 @@ inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedG
     w.keep_hi = keep_hi;
     hipExtLaunchKernelGGL(p2g_mass_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, ev_start,
                           ev_stop, 0, w, g, P);
-    hipLaunchKernelGGL(straggler_p2g_kernel<2>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
+    hipLaunchKernelGGL(straggler_p2g_team_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
     return 0;
 }
 
@@ -1248,11 +1382,12 @@ inline int launch_p2g_momentum_tiled(TiledState &T, StoreSel st, long long n, Fi
                                      hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
                                      StagePart sp = kWholeStage)
 {
+    if (sp.part != 1) T.listed = T.stage_parity;      // with part 2 the list is complete
     const TiledWork w = tiled_work(T, st, n, sp);
     hipExtLaunchKernelGGL(p2g_momentum_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream,
                           ev_start, ev_stop, 0, w, g, P);
     if (sp.part != 1)
-        hipLaunchKernelGGL(straggler_p2g_kernel<3>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
+        hipLaunchKernelGGL(straggler_p2g_team_kernel<true>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
     return 0;
 }
 
@@ -1262,18 +1397,33 @@ inline int launch_g2p_tiled(TiledState &T, StoreSel st, long long n, const float
                             StagePart sp = kWholeStage)
 {
     const dim3 grid(item_bound(T, n)), block(kTiledThreads);
-    const TiledWork w = tiled_work(T, st, n, sp);
-    if (modes) {
-        hipExtLaunchKernelGGL(g2p_tiled_kernel<true>, grid, block, 0, stream, ev_start, ev_stop, 0, w, cellf, P, modes);
-        if (sp.part != 1)
-            hipLaunchKernelGGL(straggler_g2p_kernel<true>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, cellf, P,
-                               modes);
+    // With a list of this step's stragglers at hand (TiledState::listed) the stage counts into no
+    // counter of its own: its follow-up kernel reads that list, and the next stage finds the counters
+    // as the momentum pass left them.
+    const bool listed = T.listed >= 0;
+    TiledWork w;
+    if (listed) {
+        w = tiled_work(T, st, n, StagePart{1, sp.bnd_lo, sp.bnd_hi});      // part 1: no change of counter
+        w.part = sp.part;
+        w.sg = Stragglers{T.straggler_counts + T.listed, T.straggler_counts + (T.listed ^ 1), T.straggler_list};
     } else {
-        hipExtLaunchKernelGGL(g2p_tiled_kernel<false>, grid, block, 0, stream, ev_start, ev_stop, 0, w, cellf, P, modes);
-        if (sp.part != 1)
-            hipLaunchKernelGGL(straggler_g2p_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, cellf, P,
-                               modes);
+        w = tiled_work(T, st, n, sp);
     }
+#define FLOWMPM_G2P_LAUNCH(MODES_, LISTED_)                                                                       \
+    do {                                                                                                          \
+        hipExtLaunchKernelGGL((g2p_tiled_kernel<MODES_, LISTED_>), grid, block, 0, stream, ev_start, ev_stop, 0,  \
+                              w, cellf, P, modes);                                                                \
+        if (sp.part != 1)                                                                                         \
+            hipLaunchKernelGGL(straggler_g2p_kernel<MODES_>, dim3(kStragglerBlocks), dim3(256), 0, stream, w,     \
+                               cellf, P, modes);                                                                  \
+    } while (0)
+    if (modes) {
+        if (listed) FLOWMPM_G2P_LAUNCH(true, true); else FLOWMPM_G2P_LAUNCH(true, false);
+    } else {
+        if (listed) FLOWMPM_G2P_LAUNCH(false, true); else FLOWMPM_G2P_LAUNCH(false, false);
+    }
+#undef FLOWMPM_G2P_LAUNCH
+    if (sp.part != 1) T.listed = -1;                  // the particles have moved
     return 0;
 }
 

@@ -172,6 +172,7 @@ class Handle:
         out = {names[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(len(names))}
         out["rebin"]["performed"] = t.launches[_lib.TIMING_REBINS_DONE]
         out["rebin"]["performed_ms"] = t.ms[_lib.TIMING_REBINS_DONE]      # device clock, every step
+        out["rebin"]["stragglers"] = t.launches[_lib.TIMING_STRAGGLERS]     # particles, summed over the g2p stages
         return out
 
     # ---- slab decomposition ----

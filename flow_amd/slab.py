@@ -234,6 +234,7 @@ class SlabSimulation:
         b = self.backend
         masks = (_lib.COMP_MASS, _lib.COMP_MOMENTUM)
         self._pending_counts = None
+        self.migrated_out = 0       # particles this rank has sent away so far
         self._send = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
         self._recv = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
 
@@ -352,6 +353,7 @@ class SlabSimulation:
         b = self.backend
         matrix = self._all_gather_counts(counts_dev, self._comm_device())
         counts = matrix[self.rank]
+        self.migrated_out += int(counts.sum())
         packed = b.pack_leavers(counts)
         if not matrix.any():
             return
@@ -386,9 +388,9 @@ class SlabSimulation:
             self._begin_migration()
             return
         # The library's tiled stages in parts, so that neither the host's wait for the migration
-        # counts nor a halo exchange leaves the GPU without work:
-        # so does the mass pass of the particles that stay; the leavers are skipped on the device,
-        # the arrivals added once they are in
+        # counts nor a halo exchange leaves the GPU without work.  The mass pass of the particles
+        # that stay runs while the counts travel: the leavers are skipped on the device, the
+        # arrivals added once they are in.
         b.run_kernel(_lib.KERNEL_P2G_MASS_STAYERS)
         if self._pending_counts is not None:
             b.refind_leavers(self.plane_starts)

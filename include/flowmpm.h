@@ -83,6 +83,9 @@ extern "C" {
 #define FLOWMPM_TIMING_REBINS_DONE  6   /* the re-bins the device actually performed: launches[] their number,
                                           ms[] the device time they took (device wall clock, every step,
                                           whatever the profiling stride) */
+#define FLOWMPM_TIMING_STRAGGLERS   7   /* launches[]: particles the tiled g2p stages found outside their tile's
+                                          arena (or past the binned range) and handed to the follow-up kernels,
+                                          summed over the steps; ms[] unused */
 #define FLOWMPM_TIMING_SLOTS        8
 
 /* How the particle-to-grid scatter is organised. */
@@ -312,7 +315,8 @@ int flowmpm_extract_leavers(flowmpm_sim *sim, const int32_t *plane_starts, int32
  * the caller (host memory) once it has read them, packs the records and compacts the store.
  * Between the two calls only clearGrid and FLOWMPM_KERNEL_P2G_MASS_STAYERS may run; as that stage
  * may re-bin (move) the particles, flowmpm_find_leavers is then called once more before the pack
- * (dev_counts may be NULL: the counts are the same). */
+ * with dev_counts NULL (the counts are the same): that call repeats the classification only if a
+ * re-bin has happened since the first one, which the device decides. */
 int flowmpm_find_leavers(flowmpm_sim *sim, const int32_t *plane_starts, int32_t n_ranks, void *dev_counts);
 int flowmpm_pack_leavers(flowmpm_sim *sim, const int64_t *counts, int32_t n_ranks, void *dev_out,
                          int64_t capacity_records);
