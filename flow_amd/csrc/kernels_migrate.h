@@ -45,48 +45,54 @@ find_prologue_kernel(int *counters, const int *epoch, int only_if_moved)
     if (threadIdx.x == 0) { counters[kRedoWord] = redo ? 1 : 0; counters[kEpochWord] = now; }
 }
 
-// Leavers are few and sit next to each other in the store (they come from the boundary tiles), so the
-// lanes of a wave share their atomics: one on the total, one per destination present in the wave.
+// Every leaver needs a place in the list and a rank among those bound for its destination: three
+// counters for the whole launch.  Atomics on one word are served one after the other and each waits
+// for its return value, so a workgroup collects its leavers in LDS first -- it reads one contiguous
+// run of the store -- and reserves its share of each counter with one atomic.  What does not fit the
+// buffer takes the counters directly.
+constexpr int kFindBuf = 1024;
+
 __global__ void __launch_bounds__(256)
 find_leavers_kernel(StoreSel ss, long long n, int x0, int nx, RankTable rt, int *counters,
                     int *list_slot, int *list_dest, int *list_k, long long list_cap)
 {
     if (counters[kRedoWord] == 0) return;
+    __shared__ int buf_slot[kFindBuf], buf_dest_k[kFindBuf];     // destination | rank within this workgroup << 6
+    __shared__ int n_buf, per_dest[kMaxRanks], base_dest[kMaxRanks], base_e;
+    static_assert(kMaxRanks <= 64, "the destination is packed into 6 bits");
+    if (threadIdx.x == 0) n_buf = 0;
+    if (threadIdx.x < kMaxRanks) per_dest[threadIdx.x] = 0;
+    __syncthreads();
     const Store st = ss.pick();
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = (1ULL << lane) - 1ULL;
-    // every lane of a wave runs the same rounds (the ballots and shuffles need the whole wave)
-    for (long long j0 = (long long)blockIdx.x * blockDim.x; j0 < n; j0 += (long long)gridDim.x * blockDim.x) {
-        const long long j = j0 + threadIdx.x;
-        bool leaver = false;
+    const long long per = (((n + gridDim.x - 1) / gridDim.x) + 255) / 256 * 256;
+    const long long begin = (long long)blockIdx.x * per, end = n < begin + per ? n : begin + per;
+    for (long long j = begin + threadIdx.x; j < end; j += blockDim.x) {
+        const float px = st.slot(kPosX)[j];
+        if (!is_leaver(px, x0, nx)) continue;
+        const int ix = f32_to_i32(px);
         int dest = 0;
-        if (j < n) {
-            const float px = st.slot(kPosX)[j];
-            leaver = is_leaver(px, x0, nx);
-            if (leaver) {
-                const int ix = f32_to_i32(px);
-                for (int r = 0; r < rt.n; r++)
-                    if (ix >= rt.starts[r]) dest = r;
-            }
+        for (int r = 0; r < rt.n; r++)
+            if (ix >= rt.starts[r]) dest = r;
+        const int i = atomicAdd(&n_buf, 1);
+        if (i < kFindBuf) {
+            buf_slot[i] = (int)j;
+            buf_dest_k[i] = dest | (atomicAdd(&per_dest[dest], 1) << 6);
+        } else {
+            const int k = atomicAdd(&counters[dest], 1);
+            const int e = atomicAdd(&counters[kMaxRanks], 1);
+            if (e < list_cap) { list_slot[e] = (int)j; list_dest[e] = dest; list_k[e] = k; }
         }
-        const unsigned long long all = __ballot(leaver);
-        if (all == 0) continue;                            // the whole wave
-        const int first = __ffsll((long long)all) - 1;
-        int e = 0;
-        if (lane == first) e = atomicAdd(&counters[kMaxRanks], __popcll(all));
-        e = __shfl(e, first) + __popcll(all & below);
-        int k = 0;
-        for (unsigned long long rest = all; rest != 0;) {  // uniform: one round per destination present
-            const int leader = __ffsll((long long)rest) - 1;
-            const int d = __shfl(dest, leader);
-            const unsigned long long same = __ballot(leaver && dest == d);
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&counters[d], __popcll(same));
-            base = __shfl(base, leader);
-            if (leaver && dest == d) k = base + __popcll(same & below);
-            rest &= ~same;
-        }
-        if (leaver && e < list_cap) { list_slot[e] = (int)j; list_dest[e] = dest; list_k[e] = k; }
+    }
+    __syncthreads();
+    const int cnt = n_buf < kFindBuf ? n_buf : kFindBuf;
+    if (cnt == 0) return;                                  // uniform
+    if (threadIdx.x < rt.n && per_dest[threadIdx.x] > 0)
+        base_dest[threadIdx.x] = atomicAdd(&counters[threadIdx.x], per_dest[threadIdx.x]);
+    if (threadIdx.x == 128) base_e = atomicAdd(&counters[kMaxRanks], cnt);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const int e = base_e + i, dest = buf_dest_k[i] & 63;
+        if (e < list_cap) { list_slot[e] = buf_slot[i]; list_dest[e] = dest; list_k[e] = base_dest[dest] + (buf_dest_k[i] >> 6); }
     }
 }
 
@@ -186,8 +192,8 @@ inline int migration_reserve(MigrationScratch &M, long long want, std::string *m
     return 0;
 }
 
-// Workgroups of find_leavers_kernel: enough to fill the chip, each with several rounds of 256 particles.
-inline unsigned find_blocks(long long n) { return (unsigned)std::min<long long>((n + 255) / 256, 4096); }
+// Workgroups of find_leavers_kernel: enough to fill the chip, few enough that the counters see few atomics.
+inline unsigned find_blocks(long long n) { return (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 1024)); }
 
 // Enqueues the classification of the n resident particles: leaver counts per destination
 // rank and the leaver list.  Nothing is read back here.  dev_counts (may be null) receives
@@ -203,7 +209,8 @@ inline int find_leavers(MigrationScratch &M, StoreSel st, long long n, int x0, i
         *msg = "no classification of these particles is in flight";
         return 3;
     }
-    if (migration_reserve(M, std::max<long long>(M.list_cap, 4096), msg)) return 1;
+    // room for 1/64 of the particles to leave in one step; pack_leavers doubles it when that is not enough
+    if (migration_reserve(M, std::max<long long>(M.list_cap, std::max<long long>(4096, n / 64)), msg)) return 1;
     M.table = RankTable{};
     M.table.n = n_ranks;
     for (int r = 0; r <= n_ranks; r++) M.table.starts[r] = plane_starts[r];
@@ -238,7 +245,8 @@ inline int pack_leavers(MigrationScratch &M, StoreSel st, long long n, int x0, i
     hipError_t e;
     if (total > M.list_cap) {
         // the list overflowed: grow it and classify again (positions have not changed since)
-        if (migration_reserve(M, total, msg)) return 1;
+        // (with headroom: growing means freeing, which waits for the device)
+        if (migration_reserve(M, 2 * total, msg)) return 1;
         hipLaunchKernelGGL(find_prologue_kernel, dim3(1), dim3(128), 0, stream, M.counters,
                            static_cast<const int *>(nullptr), 0);
         const long long cap = M.list_cap;

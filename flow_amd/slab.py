@@ -234,6 +234,12 @@ class SlabSimulation:
         b = self.backend
         masks = (_lib.COMP_MASS, _lib.COMP_MOMENTUM)
         self._pending_counts = None
+        self._pending_matrix = None
+        self._count_bufs = None
+        # RCCL on device tensors: the count exchange starts right after the classification
+        # (FLOWMPM_SLAB_EARLY_COUNTS=0 keeps it where the counts are needed, for A/B runs)
+        self.early_counts = (self.transport is not None and not self.transport.stage and backend is None
+                             and os.environ.get("FLOWMPM_SLAB_EARLY_COUNTS", "1") != "0")
         self.migrated_out = 0       # particles this rank has sent away so far
         self._send = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
         self._recv = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
@@ -344,6 +350,28 @@ class SlabSimulation:
         if self.transport is None:
             return
         self._pending_counts = self.backend.find_leavers(self.plane_starts)
+        if self.early_counts:
+            self._pending_matrix = self._start_count_gather(self._pending_counts)
+
+    def _start_count_gather(self, counts_dev):
+        """The count exchange and its copy to the host, started as soon as the classification is
+        enqueued and kept off the stream the kernels run on: by the time the next step needs the
+        matrix it has long arrived, and the host never waits with an empty queue behind it."""
+        dev = self.backend.torch_device
+        if self._count_bufs is None:
+            self._count_bufs = (torch.empty(self.world * self.world, dtype=torch.int64, device=dev),
+                                torch.empty(self.world * self.world, dtype=torch.int64).pin_memory(),
+                                torch.cuda.Stream(device=dev))
+        out, host, side = self._count_bufs
+        work = self.dist.all_gather_into_tensor(out, counts_dev, async_op=True)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            if work is not None:
+                work.wait()                     # the side stream waits for the collective, not the host
+            host.copy_(out, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        return done
 
     def _finish_migration(self):
         """Completes the migration begun after the last g2p (a no-op when none is pending)."""
@@ -351,7 +379,12 @@ class SlabSimulation:
         if counts_dev is None:
             return
         b = self.backend
-        matrix = self._all_gather_counts(counts_dev, self._comm_device())
+        done, self._pending_matrix = self._pending_matrix, None
+        if done is not None:
+            done.synchronize()
+            matrix = self._count_bufs[1].numpy().reshape(self.world, self.world).copy()
+        else:
+            matrix = self._all_gather_counts(counts_dev, self._comm_device())
         counts = matrix[self.rank]
         self.migrated_out += int(counts.sum())
         packed = b.pack_leavers(counts)

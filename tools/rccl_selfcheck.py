@@ -36,6 +36,20 @@ def main():
     dist.all_gather_into_tensor(out, torch.tensor([3, 1, 4, 1], dtype=torch.int64, device=dev))
     report["all_gather_into_tensor"] = out.cpu().tolist() == [3, 1, 4, 1]
 
+    # the slab step's count exchange: asynchronous, finished and copied to pinned memory on a side stream
+    side = torch.cuda.Stream(device=dev)
+    out2 = torch.empty(4, dtype=torch.int64, device=dev)
+    host = torch.empty(4, dtype=torch.int64).pin_memory()
+    work = dist.all_gather_into_tensor(out2, torch.tensor([2, 7, 1, 8], dtype=torch.int64, device=dev), async_op=True)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        work.wait()
+        host.copy_(out2, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(side)
+    done.synchronize()
+    report["all_gather_async_side_stream"] = host.tolist() == [2, 7, 1, 8]
+
     e = torch.tensor([1.5], dtype=torch.float64, device=dev)
     dist.all_reduce(e, op=dist.ReduceOp.MAX)
     report["all_reduce_max_f64"] = float(e.item()) == 1.5

@@ -49,7 +49,7 @@ class FakeDist:
                 op.tensor.zero_()
         return [_Done()]
 
-    def all_gather_into_tensor(self, out, t):
+    def all_gather_into_tensor(self, out, t, async_op=False):
         out.zero_()
         out[: t.numel()] = t
 
