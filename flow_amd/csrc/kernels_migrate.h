@@ -66,21 +66,33 @@ find_leavers_kernel(StoreSel ss, long long n, int x0, int nx, RankTable rt, int 
     const Store st = ss.pick();
     const long long per = (((n + gridDim.x - 1) / gridDim.x) + 255) / 256 * 256;
     const long long begin = (long long)blockIdx.x * per, end = n < begin + per ? n : begin + per;
-    for (long long j = begin + threadIdx.x; j < end; j += blockDim.x) {
-        const float px = st.slot(kPosX)[j];
-        if (!is_leaver(px, x0, nx)) continue;
-        const int ix = f32_to_i32(px);
-        int dest = 0;
-        for (int r = 0; r < rt.n; r++)
-            if (ix >= rt.starts[r]) dest = r;
-        const int i = atomicAdd(&n_buf, 1);
-        if (i < kFindBuf) {
-            buf_slot[i] = (int)j;
-            buf_dest_k[i] = dest | (atomicAdd(&per_dest[dest], 1) << 6);
-        } else {
-            const int k = atomicAdd(&counters[dest], 1);
-            const int e = atomicAdd(&counters[kMaxRanks], 1);
-            if (e < list_cap) { list_slot[e] = (int)j; list_dest[e] = dest; list_k[e] = k; }
+    // four loads in flight per thread; a slot past the run reads as a position inside the slab
+    const float inside = (float)x0 + 0.5f;
+    for (long long j0 = begin + threadIdx.x; j0 < end; j0 += 4 * blockDim.x) {
+        float x4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long q = j0 + (long long)u * blockDim.x;
+            x4[u] = q < end ? st.slot(kPosX)[q] : inside;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long j = j0 + (long long)u * blockDim.x;
+            const float px = x4[u];
+            if (!is_leaver(px, x0, nx)) continue;
+            const int ix = f32_to_i32(px);
+            int dest = 0;
+            for (int r = 0; r < rt.n; r++)
+                if (ix >= rt.starts[r]) dest = r;
+            const int i = atomicAdd(&n_buf, 1);
+            if (i < kFindBuf) {
+                buf_slot[i] = (int)j;
+                buf_dest_k[i] = dest | (atomicAdd(&per_dest[dest], 1) << 6);
+            } else {
+                const int k = atomicAdd(&counters[dest], 1);
+                const int e = atomicAdd(&counters[kMaxRanks], 1);
+                if (e < list_cap) { list_slot[e] = (int)j; list_dest[e] = dest; list_k[e] = k; }
+            }
         }
     }
     __syncthreads();
