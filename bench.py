@@ -41,9 +41,10 @@ def parse_args():
     ap.add_argument("--grid", type=str, default="", help="override the N=1 grid, e.g. 128,128,128")
     ap.add_argument("--scene", choices=("ellipsoid", "dam_break"), default="ellipsoid")
     ap.add_argument("--mode", default="chaos",
-                    choices=("chaos", "front_gravity_cylinder", "sphere", "polygon", "color_spheres", "segment",
-                             "image_grid", "everything"),
-                    help="display mode whose g2p forces run in the timed steps (N=1 only)")
+                    choices=("chaos", "modes_off", "front_gravity_cylinder", "sphere", "polygon", "color_spheres",
+                             "segment", "image_grid", "everything"),
+                    help="display mode whose g2p forces run in the timed steps (N=1 only); modes_off runs the "
+                         "kernel that holds the mode branches with every mode switched off")
     ap.add_argument("--timing-stride", type=int, default=8,
                     help="HIP events on the kernels of every k-th timed step (1 = every step)")
     ap.add_argument("--noise", type=float, default=0.0,
