@@ -131,9 +131,9 @@ def test_default_scene_digest(algo):
 @pytest.mark.parametrize("case", ["fast", "crowded"])
 def test_long_run_on_one_binning(oracle_binding, monkeypatch, case):
     """No re-bin after the first one (the drift rule is off and the interval is never reached):
-    particles that leave their tile's arena are adopted by the tile they move into, or -- when
-    its list is full or it has no work item -- go to the global grids.  Every route must give
-    the reference's bits, for as long as the run lasts."""
+    every particle that leaves its tile's arena goes through the follow-up kernels (32 lanes to a
+    particle in the two p2g passes, the momentum pass's list reused by g2p) for as long as the
+    run lasts, and must still give the reference's bits."""
     monkeypatch.setenv("FLOWMPM_DRIFT_DIVISOR", "0")
     if case == "fast":
         grid, n, steps = (40, 24, 16), 6000, 60
@@ -153,7 +153,38 @@ def test_long_run_on_one_binning(oracle_binding, monkeypatch, case):
         orc.run(want, u, 10, 0.0)
         assert np.array_equal(h.download_grid_i32(), orc.cell), "fixed-point grid after %d steps" % (10 * chunk + 10)
         assert_bits_equal(h.download_particles(), want, "particles after %d steps" % (10 * chunk + 10))
-    assert h.timings()["rebin"]["performed"] == 1
+    t = h.timings()["rebin"]
+    assert t["performed"] == 1
+    assert t["stragglers"] > n, "the case must send particles through the follow-up kernels"
+    h.close()
+
+
+def test_g2p_lists_its_own_stragglers_when_no_momentum_pass_did(oracle_binding):
+    """g2p skips the particles outside their arena that the momentum pass (or p2g2) of the same
+    step listed.  Run on its own -- here a second time on the same float grid, and once right
+    after the particles were replaced -- it has no such list and must build one."""
+    grid, n = (40, 24, 16), 6000
+    rec = moving_particles(n, grid, seed=53, vel=3.0)
+    h = _handle(grid, rec, _lib.ALGO_TILED, rebin_interval=100000)
+    orc = oracle_binding.Oracle(grid)
+    want = rec.copy()
+    u = oracle_binding.make_uniforms(grid, n, **DEFAULT_UNIFORMS)
+    for k in range(8):
+        for kern in (_lib.KERNEL_CLEAR_GRID, _lib.KERNEL_P2G_MASS, _lib.KERNEL_P2G_MOMENTUM, _lib.KERNEL_UPDATE_GRID,
+                     _lib.KERNEL_G2P, _lib.KERNEL_G2P):
+            h.run_kernel(kern)
+        orc.clear_grid(); orc.p2g1(want, u); orc.p2g2(want, u); orc.update_grid(u)
+        orc.g2p(want, u); orc.g2p(want, u)
+        assert_bits_equal(h.download_particles(), want, "particles after step %d" % k)
+    assert h.timings()["rebin"]["stragglers"] > 0
+    # the same particles uploaded again: the list of the last momentum pass is void
+    h.run_kernel(_lib.KERNEL_CLEAR_GRID); h.run_kernel(_lib.KERNEL_P2G_MASS); h.run_kernel(_lib.KERNEL_P2G_MOMENTUM)
+    h.run_kernel(_lib.KERNEL_UPDATE_GRID)
+    orc.clear_grid(); orc.p2g1(want, u); orc.p2g2(want, u); orc.update_grid(u)
+    h.upload_particles(want)
+    h.run_kernel(_lib.KERNEL_G2P)
+    orc.g2p(want, u)
+    assert_bits_equal(h.download_particles(), want, "particles after g2p on re-uploaded particles")
     h.close()
 
 
