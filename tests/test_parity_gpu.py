@@ -139,8 +139,8 @@ def test_long_run_on_one_binning(oracle_binding, monkeypatch, case):
         grid, n, steps = (40, 24, 16), 6000, 60
         rec = moving_particles(n, grid, seed=77, vel=3.0)
     else:
-        # a block of fluid that fills a few tiles and spreads into empty ones: hundreds of
-        # particles enter tiles that have no work item, and adoption lists overflow
+        # a block of fluid that fills a few tiles and spreads into empty ones: thousands of
+        # particles end up in tiles that have no work item
         grid, n, steps = (32, 32, 32), 20000, 40
         rec = moving_particles(n, grid, seed=78, vel=2.5)
         rec[:, 0:3] = 10.0 + (rec[:, 0:3] - 2.0) * (9.0 / 28.0)
