@@ -1278,7 +1278,10 @@ inline void tiled_free(TiledState &T)
 
 // Blocks of the grid-stride binning kernels: enough to fill the chip, few enough that a
 // launch which finds no re-bin due costs next to nothing.
-constexpr unsigned kBinBlocks = 2048;
+#ifndef FLOWMPM_BIN_BLOCKS
+#define FLOWMPM_BIN_BLOCKS 2048
+#endif
+constexpr unsigned kBinBlocks = FLOWMPM_BIN_BLOCKS;
 
 // Enqueues the start-of-step pair of launches (see "binning" above).  When a re-bin is due the
 // first n particles of the current store are grouped by tile into the other store, the work
