@@ -388,6 +388,7 @@ int stage_g2p(flowmpm_sim *s, int part = 0)
     if (part != 0 && !(s->slab && is_tiled(s)))
         return fail(s, FLOWMPM_ERR_INVALID, "interior / boundary parts are for tiled slab handles");
     if (is_tiled(s) && (rc = stage_rebin_if_needed(s))) return rc;
+    s->migration.classified = -1;      // g2p moves the particles: a leaver classification made before it is void
     const mpm::ModeParams *modes = nullptr;
     if (any_mode_on(s)) {
         if (s->modes_stale || s->modes_for_live != s->live) {
