@@ -8,7 +8,7 @@ The dynamics near the cuts are therefore not the real ones; the amount of work p
 planes, particles, work items and the time per step, and the ratio max / mean that bounds the weak
 scaling efficiency of the real run from above.
 
-    python tools/slab_balance.py --world 8 [--starts 0,140,...,512] [--tile-weight W]
+    python tools/slab_balance.py --world 8 [--starts 0,140,...,512] [--only SLAB]
 """
 import argparse
 import os
@@ -92,8 +92,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--only", type=int, default=-1, help="run this slab alone (for a profiler)")
     ap.add_argument("--starts", default="", help="comma-separated plane starts instead of the balanced ones")
-    ap.add_argument("--tile-weight", type=float, default=None,
-                    help="cut by particles + W x occupied 8x8x8 tiles per plane instead of particles alone")
     args = ap.parse_args()
 
     world, n_per = args.world, 1 << args.particles_log2
@@ -104,9 +102,6 @@ def main():
     x_all = np.concatenate([c[:, 0] for c in chunks])
     if args.starts:
         starts = [int(s) for s in args.starts.split(",")]
-    elif args.tile_weight is not None:
-        from flow_amd.slab import weighted_plane_starts
-        starts = weighted_plane_starts(np.concatenate([c[:, 0:3] for c in chunks]), grid, world, args.tile_weight)
     else:
         starts = balanced_plane_starts(x_all, grid[0], world)
     assert len(starts) == world + 1 and starts[0] == 0 and starts[-1] == grid[0]
