@@ -114,3 +114,5 @@ def test_the_two_rank_line_over_gloo():
     assert set(ROOFLINE_KEYS) <= set(d["roofline"])
     assert len(d["config"]["kernel_ms_per_step_per_rank"]) == 2
     assert d["config"]["kernel_time_imbalance_max_over_mean"] >= 1.0
+    assert len(d["config"]["rebins_per_rank"]) == 2 and min(d["config"]["rebins_per_rank"]) >= 0
+    assert len(d["config"]["particles_sent_away_per_step_per_rank"]) == 2
