@@ -30,6 +30,7 @@ pieces) and to `torch.distributed`, so the protocol itself is exercised on CPU w
 gloo backend in the tests, and runs on GPUs with `GpuSlabBackend`.
 """
 import os
+import sys
 
 import numpy as np
 import torch
@@ -351,7 +352,15 @@ class SlabSimulation:
             return
         self._pending_counts = self.backend.find_leavers(self.plane_starts)
         if self.early_counts:
-            self._pending_matrix = self._start_count_gather(self._pending_counts)
+            try:
+                self._pending_matrix = self._start_count_gather(self._pending_counts)
+            except (RuntimeError, TypeError, NotImplementedError) as exc:
+                # every rank runs the same library, so every rank lands here together; the
+                # exchange then happens where the counts are needed
+                print("flow_amd.slab: early count exchange unavailable (%s); using the blocking one"
+                      % (str(exc).splitlines()[0] if str(exc) else type(exc).__name__), file=sys.stderr)
+                self.early_counts = False
+                self._pending_matrix = None
 
     def _start_count_gather(self, counts_dev):
         """The count exchange and its copy to the host, started as soon as the classification is
