@@ -8,6 +8,8 @@ timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpur
 bash tools/pmc.sh ${TAG}_fetch TCC_EA0_RDREQ_32B_sum FETCH_SIZE
 bash tools/pmc.sh ${TAG}_write WRITE_SIZE TCC_EA0_WRREQ_64B_sum
 bash tools/pmc.sh ${TAG}_sq SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-for t in fetch write sq; do python tools/pmc_summary.py gpurun_out/pmc_${TAG}_$t > gpurun_out/$TAG/pmc_$t.txt; done
+bash tools/pmc.sh ${TAG}_atomic TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum
+for t in fetch write sq atomic; do python tools/pmc_summary.py gpurun_out/pmc_${TAG}_$t > gpurun_out/$TAG/pmc_$t.txt; done
+timeout -k 10 300 python bench.py --no-cpu-baseline --rounds 5 > gpurun_out/$TAG/bench_rounds5.json 2>> gpurun_out/$TAG/bench.err
 cp $(find gpurun_out/$TAG/stats -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/kernel_stats_16M_256cube.csv
 echo done
