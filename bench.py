@@ -13,6 +13,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,6 +40,8 @@ def parse_args():
     ap.add_argument("--rebin-interval", type=int, default=64,
                     help="upper bound of the steps between re-bins; the device re-bins earlier when particles drift")
     ap.add_argument("--particles-log2", type=int, default=24, help="particles per GPU = 2^k")
+    ap.add_argument("--particles", type=int, default=0,
+                    help="N=1: an exact particle count instead of 2^k (the reference's default scene has 81,920)")
     ap.add_argument("--grid", type=str, default="", help="override the N=1 grid, e.g. 128,128,128")
     ap.add_argument("--scene", choices=("ellipsoid", "dam_break"), default="ellipsoid")
     ap.add_argument("--mode", default="chaos",
@@ -52,6 +56,11 @@ def parse_args():
     ap.add_argument("--rounds", type=int, default=1,
                     help="N=1: time the K steps this many times back to back; the line reports the first as "
                          "`value` and all of them, with median and minimum, under `rounds`")
+    ap.add_argument("--steady-windows", type=int, default=3,
+                    help="N=1: after the timed K steps, this many further windows of --steady-steps steps each are "
+                         "timed in the same process (the `steady` object: the step with its share of re-bins, "
+                         "whatever K was); 0 switches it off")
+    ap.add_argument("--steady-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4,
                     help="steps of the same workload the CPU oracle is timed on (about 12 s on 16 threads)")
@@ -171,32 +180,48 @@ def roofline_of(timings, n, cells):
     The tiled path runs p2g1 + p2g2 as a mass pass and a summed-momentum pass, which moves work
     (and bytes) from the first launch to the second; the reference's algorithmic bytes are defined
     for the pair, so when one of the two passes is the longest launch the pair is judged together
-    as "p2g": 116 N + 32 G bytes over the sum of the two average launch durations."""
-    out, avg = {}, {}
+    as "p2g": 116 N + 32 G bytes over the sum of the two average launch durations.
+
+    Only "p2g" and "g2p" carry a fraction in the per-kernel table: clearGrid and updateGrid visit the
+    dirty tiles only and the two p2g launches split the work differently from the reference's stages,
+    so the all-cells / per-stage numerators say nothing about those launches one by one."""
+    full, avg = {}, {}
     for name, (bp, bc) in BYTES.items():
         t = timings[name]
         if t["launches"] == 0:
             continue
         avg[name] = t["ms"] / t["launches"]
         gbs = (bp * n + bc * cells) / (avg[name] * 1e-3) / 1e9
-        out[name] = {"avg_ms": round(avg[name], 4), "algorithmic_GBs": round(gbs, 1),
-                     "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        full[name] = {"avg_ms": round(avg[name], 4), "algorithmic_GBs": round(gbs, 1),
+                      "frac": round(gbs / HBM_PEAK_GBS, 4)}
     if "p2g1" in avg and "p2g2" in avg:
         ms = avg["p2g1"] + avg["p2g2"]
         gbs = (116 * n + 32 * cells) / (ms * 1e-3) / 1e9
-        out["p2g"] = {"avg_ms": round(ms, 4), "algorithmic_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        full["p2g"] = {"avg_ms": round(ms, 4), "algorithmic_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
     name = max(avg, key=avg.get)
-    if name in ("p2g1", "p2g2") and "p2g" in out:
+    if name in ("p2g1", "p2g2") and "p2g" in full:
         name = "p2g"
-    roof = {"bound": "hbm", "kernel": name, "achieved": out[name]["algorithmic_GBs"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": out[name]["frac"], "traffic": None, "avg_launch_ms": out[name]["avg_ms"]}
+    roof = {"bound": "hbm", "kernel": name, "achieved": full[name]["algorithmic_GBs"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": full[name]["frac"], "traffic": None, "avg_launch_ms": full[name]["avg_ms"]}
+    out = {k: (v if k in ("p2g", "g2p") else {"avg_ms": v["avg_ms"]}) for k, v in full.items()}
+    if "p2g" in full and "g2p" in full:
+        ms = full["p2g"]["avg_ms"] + full["g2p"]["avg_ms"]
+        gbs = (212 * n + 48 * cells) / (ms * 1e-3) / 1e9
+        out["p2g+g2p"] = {"avg_ms": round(ms, 4), "algorithmic_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
     return roof, out
+
+
+def with_sort(p2g_avg_ms, rebin_ms_per_step, n, cells):
+    """P2G with the particle sort (the re-bins the device performed) amortised over the steps."""
+    ms = p2g_avg_ms + rebin_ms_per_step
+    gbs = (116 * n + 32 * cells) / (ms * 1e-3) / 1e9
+    return {"avg_ms": round(ms, 4), "algorithmic_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
 
 
 def run_single(args):
     import flow_amd
     from flow_amd import _lib
-    n = 1 << args.particles_log2
+    n = args.particles if args.particles > 0 else 1 << args.particles_log2
     grid = tuple(int(x) for x in args.grid.split(",")) if args.grid else (256, 256, 256)
     cells = grid[0] * grid[1] * grid[2]
     seed = 0xF10E5EED + 3
@@ -243,21 +268,56 @@ def run_single(args):
     # Optional repeat measurements in the same process (the simulation simply goes on): `value` stays
     # the first timed region; the others are listed so that run-to-run spread can be judged.
     extra_rounds = []
+    done = args.warmup + args.steps
     for r in range(1, args.rounds):
         t1 = time.perf_counter()
-        advance(args.warmup + r * args.steps, args.steps)
+        advance(done, args.steps)
         h.synchronize()
         extra_rounds.append(n * args.steps / (time.perf_counter() - t1))
+        done += args.steps
+    # The steady state: further windows in the same process, long enough to hold the re-bins the flow
+    # needs, so that the line says what a step costs with its share of the sort whatever K was.
+    steady = None
+    if args.steady_windows > 0 and args.steady_steps > 0:
+        before = h.timings()
+        window_values = []
+        for _ in range(args.steady_windows):
+            t1 = time.perf_counter()
+            advance(done, args.steady_steps)
+            h.synchronize()
+            window_values.append(n * args.steady_steps / (time.perf_counter() - t1))
+            done += args.steady_steps
+        after = h.timings()
+        steady_steps = args.steady_windows * args.steady_steps
+        rebins = (after["rebin"].get("performed") or 0) - (before["rebin"].get("performed") or 0)
+        rebin_ms = after["rebin"].get("performed_ms", 0.0) - before["rebin"].get("performed_ms", 0.0)
+        med = float(np.median(window_values))
+        steady = {"value": round(med, 1), "unit": "particle-substeps/s", "ms_per_step": round(n / med * 1e3, 4),
+                  "steps": steady_steps, "windows": [round(v, 1) for v in window_values],
+                  "min": round(min(window_values), 1), "rebins": rebins,
+                  "rebin_ms_per_step": round(rebin_ms / steady_steps, 4),
+                  "stragglers_per_step": round(((after["rebin"].get("stragglers") or 0)
+                                                - (before["rebin"].get("stragglers") or 0)) / steady_steps, 1)}
+        steady_kernels = {name: {"ms": after[name]["ms"] - before[name]["ms"],
+                                 "launches": after[name]["launches"] - before[name]["launches"]} for name in BYTES}
     h.close()
     roof, per_kernel = roofline_of(timings, n, cells)
+    rebin_in_window = bool(timings["rebin"].get("performed"))
     if "p2g" in per_kernel and timings["rebin"].get("performed_ms") is not None:
-        # P2G with the particle sort (the re-bins) included, amortised over the timed steps
-        ms = per_kernel["p2g"]["avg_ms"] + timings["rebin"]["performed_ms"] / args.steps
-        gbs = (116 * n + 32 * cells) / (ms * 1e-3) / 1e9
-        per_kernel["p2g_with_sort"] = {"avg_ms": round(ms, 4), "algorithmic_GBs": round(gbs, 1),
-                                       "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        # P2G with the particle sort included.  From the steady windows when they ran (the timed window
+        # may be too short to hold a re-bin); otherwise from the timed window.
+        if steady is not None and all(steady_kernels[k]["launches"] for k in ("p2g1", "p2g2")):
+            p2g_ms = sum(steady_kernels[k]["ms"] / steady_kernels[k]["launches"] for k in ("p2g1", "p2g2"))
+            per_kernel["p2g_with_sort"] = dict(with_sort(p2g_ms, steady["rebin_ms_per_step"], n, cells),
+                                               window="steady")
+        else:
+            per_kernel["p2g_with_sort"] = dict(with_sort(per_kernel["p2g"]["avg_ms"],
+                                                         timings["rebin"]["performed_ms"] / args.steps, n, cells),
+                                               window="timed")
     workload_key = "%s_%d_%dx%dx%d" % (args.scene, n, grid[0], grid[1], grid[2])
     roof["traffic"] = measured_traffic(roof["kernel"], workload_key)
+    # a committed constant of an earlier counter run on this workload, not a measurement of this run
+    roof["traffic_source"] = "profiles/pmc_traffic.json" if roof["traffic"] is not None else None
     rebin = timings["rebin"]
     step_bytes = 212 * n + 112 * cells
     line = {
@@ -265,7 +325,7 @@ def run_single(args):
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+i32-fixed-point",
         "data": "synthetic",
-        "config": {"workload": "16M particles, 256^3 grid, single MI355X" if (args.particles_log2 == 24 and not args.grid)
+        "config": {"workload": "16M particles, 256^3 grid, single MI355X" if (n == 1 << 24 and not args.grid)
                    else "%d particles, grid %dx%dx%d, single MI355X" % (n, grid[0], grid[1], grid[2]),
                    "scene": args.scene, "mode": args.mode, "particles": n, "grid": list(grid),
                    "algorithm": args.algorithm,
@@ -280,6 +340,8 @@ def run_single(args):
         "kernels": per_kernel,
         # the re-binning sequence is enqueued every step and decides on the device whether to run
         # the device's own clock brackets every re-bin it performs (all steps, not only the sampled ones)
+        "rebin_in_window": rebin_in_window,
+        "steady": steady,
         "rebin": {"performed": rebin.get("performed"), "performed_ms": round(rebin.get("performed_ms", 0.0), 3),
                   "ms_per_step": round(rebin.get("performed_ms", 0.0) / args.steps, 4),
                   "timed_steps": rebin["launches"],
@@ -301,7 +363,15 @@ def run_distributed(args):
     from flow_amd.slab import SlabSimulation, balanced_plane_starts
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local_rank = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
+    n_devices = max(torch.cuda.device_count(), 1)
+    local_rank = int(os.environ.get("LOCAL_RANK", rank)) % n_devices
+    if args.dist_backend == "nccl" and n_devices < world:
+        # RCCL cannot put two ranks on one device: with fewer GPUs than ranks the run is a rehearsal of
+        # the decomposition over the host-staged transport, and the line says so (config.transport)
+        if rank == 0:
+            print("bench.py: %d ranks on %d GPU(s): using the gloo transport (rehearsal, not a scaling point)"
+                  % (world, n_devices), file=sys.stderr)
+        args.dist_backend = "gloo"
     torch.cuda.set_device(local_rank)
     if args.dist_backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -394,9 +464,38 @@ def run_distributed(args):
     return line
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` as a plain command: the ranks are started as a CHILD process
+    (torch.distributed.run, one rank per GPU) before this process has imported torch or touched
+    the GPU; rank 0's JSON line and the child's exit status are relayed."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=os.getcwd())
+    lines = child.stdout.splitlines()
+    json_lines = [l for l in lines if l.startswith("{")]
+    for l in lines:
+        if not (json_lines and l is json_lines[-1]):
+            print(l, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1])
+    sys.stdout.flush()
+    if child.returncode == 0 and not json_lines:
+        return 1
+    return child.returncode
+
+
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        raise SystemExit(spawn_ranks(args.gpus))
+    world = int(world_env or "1")
     if args.gpus > 1 or world > 1:
         if world != args.gpus:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)"

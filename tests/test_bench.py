@@ -64,6 +64,45 @@ def test_scene_uniforms_fix_the_rest_density_to_the_fill():
     assert bench.scene_uniforms(1 << 20, 128 ** 3, "ellipsoid", noise=1.0)["noise"] == 1.0
 
 
+def test_a_plain_multi_gpu_command_starts_the_ranks_as_a_child(monkeypatch, capsys):
+    """`python bench.py --gpus 2` with no WORLD_SIZE: torch.distributed.run is started as a child
+    process (never exec), with the same arguments, before torch is imported; rank 0's line and the
+    child's status are relayed."""
+    seen = {}
+
+    class Done:
+        returncode = 0
+        stdout = "some log line\n" + json.dumps({"n_gpus": 2, "value": 1.0}) + "\n"
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return Done()
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    with pytest.raises(SystemExit) as exit_info:
+        bench.main()
+    assert exit_info.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    out = capsys.readouterr()
+    assert json.loads(out.out.strip()) == {"n_gpus": 2, "value": 1.0}      # ONE line on stdout
+    assert "some log line" in out.err
+
+    class Failed(Done):
+        returncode = 7
+        stdout = ""
+    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, **kw: Failed())
+    with pytest.raises(SystemExit) as exit_info:
+        bench.main()
+    assert exit_info.value.code == 7
+
+
 def _last_json_line(text):
     lines = [l for l in text.strip().splitlines() if l.startswith("{")]
     assert lines, text[-2000:]
@@ -73,7 +112,8 @@ def _last_json_line(text):
 @pytest.mark.gpu
 def test_the_single_gpu_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2",
-                        "--particles-log2", "18", "--grid", "64,64,64", "--cpu-steps", "1", "--timing-stride", "2"],
+                        "--particles-log2", "18", "--grid", "64,64,64", "--cpu-steps", "1", "--timing-stride", "2",
+                        "--steady-windows", "2", "--steady-steps", "20"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json_line(r.stdout)
@@ -91,6 +131,14 @@ def test_the_single_gpu_line():
     cpu = d["cpu_baseline"]
     assert set(CPU_KEYS) <= set(cpu) and cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
     assert d["value"] > cpu["value"]
+    # the steady windows: the step with its share of re-bins, whatever --steps was
+    steady = d["steady"]
+    assert steady["steps"] == 2 * 20 and len(steady["windows"]) == 2 and steady["rebins"] >= 0
+    assert steady["min"] <= steady["value"] <= max(steady["windows"])
+    assert d["rebin_in_window"] == (d["rebin"]["performed"] > 0)
+    assert d["kernels"]["p2g_with_sort"]["window"] == "steady"
+    assert "frac" not in d["kernels"]["clearGrid"] and "frac" in d["kernels"]["g2p"]
+    assert roof["traffic"] is None and roof["traffic_source"] is None       # this workload was never profiled
 
 
 @pytest.mark.gpu
@@ -116,3 +164,19 @@ def test_the_two_rank_line_over_gloo():
     assert d["config"]["kernel_time_imbalance_max_over_mean"] >= 1.0
     assert len(d["config"]["rebins_per_rank"]) == 2 and min(d["config"]["rebins_per_rank"]) >= 0
     assert len(d["config"]["particles_sent_away_per_step_per_rank"]) == 2
+
+
+@pytest.mark.gpu
+def test_the_plain_two_gpu_command():
+    """`python bench.py --gpus 2 ...` exactly as a driver would type it for one GPU: no launcher, no
+    WORLD_SIZE.  On a one-GPU box the ranks share the GPU and fall back to the gloo transport."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--particles-log2", "18",
+                        "--slab-yz", "64", "--slab-x-per-gpu", "32", "--steps", "6", "--warmup", "2",
+                        "--timing-stride", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and set(LINE_KEYS) <= set(d)
+    assert sum(d["config"]["resident_per_rank_end"]) == 2 << 18
