@@ -135,6 +135,16 @@ def mode_setup(name, grid, n):
     return uni, m
 
 
+def scripted_mouse(k, grid):
+    """The dam-break configuration's scripted mouse ray at step k: a ray along +z through the centre of
+    the column whose hit point swings sinusoidally; the mouse force is the difference of the hit points
+    two frames apart over the 3-deep history (mlsMpmSimulator.js:2530-2534)."""
+    swing = 8.0 * np.sin(0.2 * np.array([k - 2, k], dtype=np.float64))
+    return dict(cursor_interaction=1, mouse_ray_direction=(0.0, 0.0, 1.0),
+                mouse_ray_origin=(0.125 * grid[0], 0.5 * grid[1], 0.0),
+                mouse_force=((swing[1] - swing[0]) / 3.0, 0.0, 0.0))
+
+
 def make_particles(scene, count, grid, seed, first_id=0):
     from flow_amd.particles import dam_break, reference_scene
     chunk = 1 << 21
@@ -250,10 +260,7 @@ def run_single(args):
             h.step(count, 0.0)
             return
         for k in range(first, first + count):
-            swing = 8.0 * np.sin(0.2 * np.array([k - 2, k], dtype=np.float64))
-            h.set_uniforms(**dict(uniforms, cursor_interaction=1, mouse_ray_direction=(0.0, 0.0, 1.0),
-                                  mouse_ray_origin=(0.125 * grid[0], 0.5 * grid[1], 0.0),
-                                  mouse_force=((swing[1] - swing[0]) / 3.0, 0.0, 0.0)))
+            h.set_uniforms(**dict(uniforms, **scripted_mouse(k, grid)))
             h.step(1, 0.0)
 
     advance(0, args.warmup)

@@ -5,7 +5,9 @@
 // and writes the AoS records.  With a schedule (JSON [[mode, frames], ...]) it calls
 // toggleGridMode(mode) before each group of frames on a scripted clock (16 ms per frame) and
 // also writes, per frame, the packed mode uniforms plus {dt, gridMode, frontGravityMode}
-// (<out>.modes, <out>.frames.json) and getColors() after the last frame (<out>.colors).
+// (<out>.modes, <out>.frames.json) and getColors() after the last frame (<out>.colors).  A schedule
+// entry [mode, frames, "image.ppm"] hands that image to toggleGridMode (modes 1, 2, 7) and writes
+// getColors() right after the toggle to <out>.colors.<entry index>.
 const fs = require('fs');
 const { MlsMpmSimulator, Conf } = require('./index');
 
@@ -22,8 +24,11 @@ const { MlsMpmSimulator, Conf } = require('./index');
     if (schedule) {
         const packs = [], info = [];
         let f = 0;
-        for (const [mode, count] of JSON.parse(schedule)) {
-            await sim.toggleGridMode(mode);
+        let entry = 0;
+        for (const [mode, count, image] of JSON.parse(schedule)) {
+            await sim.toggleGridMode(mode, image);
+            if (image) fs.writeFileSync(out + '.colors.' + entry, Buffer.from(sim.getColors().buffer));
+            entry++;
             for (let k = 0; k < count; k++, f++) {
                 now += 16;
                 await sim.update(1 / 30, 0.5 * f);

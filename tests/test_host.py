@@ -176,3 +176,26 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cc", ".js")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower().replace("test oracle", ""), os.path.join(dirpath, f)
+
+
+def test_image_mode_set_up_follows_the_reference_lines():
+    """flow_amd/modes.py's image -> grid uniforms and colour rewrite against the scalar restatement of
+    SIM:1565-1632, 2196-2266 the GPU tests drive the oracle with (tests/helpers.py)."""
+    import helpers
+    from flow_amd import modes as host_modes
+    from flow_amd.simulator import Uniform, Vector3, _Uniforms
+    u = _Uniforms()
+    u.gridMode, u.frontGravityMode = Uniform(0), Uniform(0)
+    mh = host_modes.ModeHost(u, Uniform, Vector3, clock=lambda: 1.0)
+    colors = np.zeros((8192, 3), np.float32)
+    for mode, img, n in ((1, helpers.sample_image(30, 20, 11), 6000), (7, helpers.sample_image(17, 40, 5), 6000),
+                         (2, helpers.sample_image(64, 9, 3), 777), (7, helpers.sample_image(1, 1, 0), 5)):
+        mh.currentImageMode = None
+        mh.toggle(mode, colors, n, image=img)
+        g = helpers.reference_image_grid(img.shape[1], img.shape[0], n)
+        assert (u.gridWidth.value, u.gridHeight.value) == (g["grid_width"], g["grid_height"])
+        assert (u.gridStartX.value, u.gridStartY.value) == (g["grid_start_x"], g["grid_start_y"])
+        assert (u.gridSpacingX.value, u.gridSpacingY.value) == (g["grid_spacing_x"], g["grid_spacing_y"])
+        assert u.gridMode.value == 1
+        if n > 100:
+            helpers.assert_image_mode_colors(mh.render_colors[:n], img, mode, n)

@@ -9,6 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import helpers
 from helpers import assert_bits_equal
 from flow_amd.particles import reference_scene
 
@@ -213,3 +214,47 @@ def test_js_simulator_toggle_grid_mode_matches_oracle(oracle_binding, tmp_path):
     colors = np.fromfile(out + ".colors", dtype=np.float32).reshape(particles, 3)
     assert np.array_equal(colors, rgb[np.arange(particles) % 13])
     assert [fr["frontGravityMode"] for fr in frames][6:8] == [1, 1] and frames[6]["dt"] == pytest.approx(0.4)
+
+
+@pytest.mark.gpu
+def test_js_simulator_image_modes_match_oracle(oracle_binding, tmp_path):
+    """toggleGridMode(1 | 7 | 2, image.ppm) of the JS class on the GPU.  The oracle is driven by grid
+    uniforms the test derives from the reference's lines (helpers.reference_image_grid, SIM:1565-1602),
+    not by what the JS host packed; getColors() is checked against SIM:1605-1632, 2196-2266."""
+    out = str(tmp_path / "records.bin")
+    max_particles, particles = 8192, 6000
+    wide, tall = helpers.sample_image(30, 20, 11), helpers.sample_image(17, 40, 5)
+    wide_ppm, tall_ppm = str(tmp_path / "wide.ppm"), str(tmp_path / "tall.ppm")
+    helpers.write_ppm(wide_ppm, wide)
+    helpers.write_ppm(tall_ppm, tall)
+    schedule = [[1, 3, wide_ppm], [7, 2, tall_ppm], [2, 2, wide_ppm], [0, 1]]
+    r = subprocess.run([NODE, os.path.join(ROOT, "host_js", "run_frames.js"), out, str(max_particles),
+                        str(particles), "0", json.dumps(schedule)], capture_output=True, text=True, cwd=ROOT,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import mode_cases
+    ob = oracle_binding
+    init = np.fromfile(out + ".init", dtype=np.float32).reshape(max_particles, 28)
+    got = np.fromfile(out, dtype=np.float32).reshape(max_particles, 28)
+    with open(out + ".frames.json") as f:
+        frames = json.load(f)
+    grid = (128, 64, 64)
+    orc = ob.Oracle(grid, threads=4)
+    want = init.copy()
+    rest = 0.25 * max(particles / 8192, 1)
+    k = 0
+    for entry, (mode, count, pixels) in enumerate(((1, 3, wide), (7, 2, tall), (2, 2, wide), (0, 1, None))):
+        fields = dict(mode_cases._BASE, grid_noise_strength=0.5)            # conf.gridNoiseStrength, src/conf.js:15
+        if pixels is not None:
+            fields.update(helpers.reference_image_grid(pixels.shape[1], pixels.shape[0], particles))
+            colors = np.fromfile(out + ".colors.%d" % entry, dtype=np.float32).reshape(particles, 3)
+            helpers.assert_image_mode_colors(colors, pixels, mode, particles)
+        m = mode_cases.fill(ob.ModeUniforms, fields)
+        for _ in range(count):
+            fr = frames[k]
+            assert fr["gridMode"] == (1 if pixels is not None else 0)
+            u = ob.make_uniforms(grid, particles, dt=fr["dt"], stiffness=3.0, rest_density=rest,
+                                 dynamic_viscosity=0.1, noise=1.0, time=fr["time"], grid_mode=fr["gridMode"])
+            orc.step_modes(want, u, m)
+            k += 1
+    assert_bits_equal(got[:particles, :24], want[:particles, :24], "JS host records after the image modes")

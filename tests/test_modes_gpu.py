@@ -10,6 +10,7 @@ import pytest
 import flow_amd
 import mode_cases
 from flow_amd import _lib
+import helpers
 from helpers import assert_bits_equal
 
 pytestmark = pytest.mark.gpu
@@ -196,3 +197,45 @@ def test_simulator_class_toggle_grid_mode(oracle_binding):
     sim.toggleGridMode(3)
     sim.update(0.016, elapsed)
     assert sim.uniforms.dt.value == pytest.approx(0.016 * 6 * 4.0)
+
+
+def test_simulator_class_image_modes(oracle_binding, tmp_path):
+    """toggleGridMode(1 | 7 | 2, image) end to end: image -> grid uniforms -> g2p's grid attraction on
+    the GPU.  The oracle is driven by uniforms the TEST derives from the reference's lines
+    (helpers.reference_image_grid: SIM:1565-1602), not by what the host packed, and the renderer-facing
+    colours are checked against the reference's sampling and palette matching (SIM:1605-1632,
+    2196-2266)."""
+    ob = oracle_binding
+    from flow_amd.conf import Conf
+    from flow_amd.simulator import MlsMpmSimulator
+    conf = Conf()
+    conf.maxParticles, conf.particles = 8192, 6000
+    conf.updateParams()
+    sim = MlsMpmSimulator(conf=conf, rebin_interval=2, clock=lambda: 50_000.0).init()
+    want = sim.particleBuffer.records().copy()
+    orc = ob.Oracle((128, 64, 64), threads=8)
+    wide, tall = helpers.sample_image(30, 20, 11), helpers.sample_image(17, 40, 5)
+    ppm = str(tmp_path / "tall.ppm")
+    helpers.write_ppm(ppm, tall)
+    elapsed = 0.0
+    for mode, image, pixels, frames in ((1, wide, wide, 3), (7, ppm, tall, 2), (2, wide, wide, 2), (0, None, None, 1)):
+        sim.toggleGridMode(mode, image=image)
+        fields = dict(mode_cases._BASE, grid_noise_strength=0.5)        # conf.gridNoiseStrength, src/conf.js:15
+        if pixels is not None:
+            fields.update(helpers.reference_image_grid(pixels.shape[1], pixels.shape[0], conf.particles))
+            helpers.assert_image_mode_colors(sim.getColors(), pixels, mode, conf.particles)
+        m = mode_cases.fill(ob.ModeUniforms, fields)
+        for _ in range(frames):
+            elapsed += 0.016
+            sim.update(0.016, elapsed)
+            u = ob.make_uniforms((128, 64, 64), conf.particles, dt=np.float32(0.016 * 6), stiffness=3.0,
+                                 rest_density=conf.restDensity, dynamic_viscosity=0.1, noise=1.0,
+                                 time=np.float32(elapsed), grid_mode=1 if pixels is not None else 0)
+            orc.step_modes(want, u, m)
+    got = sim.readAoS()
+    assert_bits_equal(got[:conf.particles, :24], want[:conf.particles, :24], "particles after the image modes")
+    # the grid attraction has really acted: the same frames without the toggles end elsewhere
+    plain = MlsMpmSimulator(conf=conf, rebin_interval=2, clock=lambda: 50_000.0).init()
+    for frame in range(8):
+        plain.update(0.016, 0.016 * (frame + 1))
+    assert not np.array_equal(plain.readAoS()[:conf.particles, 0:3], got[:conf.particles, 0:3])

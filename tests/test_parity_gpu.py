@@ -559,3 +559,90 @@ def test_grid_sums_match_the_downloaded_grid(oracle_binding):
     assert np.array_equal(h.grid_sums(), cell.sum(axis=0))
     assert abs(int(h.grid_sums()[3]) - n * 10_000_000) <= 27 * n      # < 1 unit lost per stencil cell
     h.close()
+
+
+def _truncated_weight_sum(pos):
+    """Sum over particles of their 27 truncated fixed-point stencil weights (SIM:307-312, 329), in
+    chunks so that the float64 temporaries stay small at 2^24 particles and more."""
+    want = 0
+    for lo in range(0, pos.shape[0], 1 << 21):
+        p = pos[lo:lo + (1 << 21)]
+        d = (p - np.floor(p)) - np.float32(0.5)
+        w = [(np.float32(0.5) * (np.float32(0.5) - d)) * (np.float32(0.5) - d), np.float32(0.75) - d * d,
+             (np.float32(0.5) * (np.float32(0.5) + d)) * (np.float32(0.5) + d)]
+        for gx in range(3):
+            for gy in range(3):
+                wxy = w[gx][:, 0] * w[gy][:, 1]
+                for gz in range(3):
+                    want += int(np.trunc(((wxy * w[gz][:, 2]) * np.float32(1e7)).astype(np.float64)).sum())
+    return want
+
+
+def _grid_mass_of(grid, particles, uni):
+    h = _handle(grid, particles, _lib.ALGO_TILED, uniforms=uni)
+    h.run_kernel(_lib.KERNEL_CLEAR_GRID)
+    h.run_kernel(_lib.KERNEL_P2G1)
+    total = int(h.grid_sums()[3])
+    h.close()
+    return total
+
+
+def test_headline_configuration_scatter_and_tiled_agree():
+    """The benchmark's headline configuration itself (2^24 particles, 256^3, bench.py's scene, seed
+    and uniforms): far beyond what the oracle finishes in a test, so the size-independent checks --
+    the reference's algorithm (scatter) and the tiled one leave identical bits in grid and particles;
+    the fixed-point grid mass equals the sum of the particles' truncated weights; and a tiled run
+    long enough to contain a re-bin the DEVICE decided on (not the interval) still equals the
+    scatter run at its end."""
+    import bench
+    grid, n = (256, 256, 256), 1 << 24
+    rec = bench.make_particles("ellipsoid", n, grid, 0xF10E5EED + 3)
+    uni = bench.scene_uniforms(n, grid[0] * grid[1] * grid[2], "ellipsoid", 0.0)
+    tiled = _handle(grid, rec, _lib.ALGO_TILED, uniforms=uni, rebin_interval=100000)
+    scatter = _handle(grid, rec, _lib.ALGO_SCATTER, uniforms=uni)
+    del rec
+    tiled.step(3, 0.0)
+    scatter.step(3, 0.0)
+    assert np.array_equal(tiled.download_grid_i32(), scatter.download_grid_i32()), "grid after 3 steps"
+    particles = tiled.download_particles()
+    assert_bits_equal(particles, scatter.download_particles(), "particles after 3 steps")
+    assert _grid_mass_of(grid, particles, uni) == _truncated_weight_sum(particles[:, 0:3])
+    del particles
+    tiled.reset_timings()
+    tiled.step(117, 0.0)
+    scatter.step(117, 0.0)
+    rebin = tiled.timings()["rebin"]
+    assert rebin["performed"] >= 1, "no device-decided re-bin in 117 steps: %r" % (rebin,)
+    assert np.array_equal(tiled.download_grid_i32(), scatter.download_grid_i32()), "grid after 120 steps"
+    assert_bits_equal(tiled.download_particles(), scatter.download_particles(), "particles after 120 steps")
+    tiled.close()
+    scatter.close()
+
+
+def test_dam_break_configuration_with_the_scripted_mouse_ray():
+    """Benchmark configuration 5 at its full size (2^25 particles in a column of a 256^3 box, about 9
+    per cell) with bench.py's scripted mouse ray changing the uniforms every step: scatter and tiled
+    agree bit for bit, the mouse force has acted, and the grid mass is the particles' truncated weights."""
+    import bench
+    grid, n = (256, 256, 256), 1 << 25
+    rec = bench.make_particles("dam_break", n, grid, 0xF10E5EED + 3)
+    uni = bench.scene_uniforms(n, grid[0] * grid[1] * grid[2], "dam_break", 0.0)
+    outs = []
+    for algo in (_lib.ALGO_TILED, _lib.ALGO_SCATTER):
+        h = _handle(grid, rec, algo, uniforms=uni, rebin_interval=100000)
+        for k in range(10):
+            h.set_uniforms(**dict(uni, **bench.scripted_mouse(k, grid)))
+            h.step(1, 0.0)
+        outs.append((h.download_grid_i32(), h.download_particles()))
+        if algo == _lib.ALGO_TILED:
+            still = _handle(grid, rec, algo, uniforms=uni, rebin_interval=100000)   # the same run, no mouse
+            still.step(10, 0.0)
+            assert not np.array_equal(still.download_field(_lib.FIELD_VELOCITY), outs[0][1][:, 4:7])
+            still.close()
+        h.close()
+    del rec
+    assert np.array_equal(outs[0][0], outs[1][0]), "dam-break grid"
+    assert_bits_equal(outs[0][1], outs[1][1], "dam-break particles")
+    particles = outs[0][1]
+    del outs
+    assert _grid_mass_of(grid, particles, uni) == _truncated_weight_sum(particles[:, 0:3])
