@@ -46,7 +46,7 @@ EXPORTS = (
     "flowmpm_plane_add_i32", "flowmpm_plane_copy_out", "flowmpm_extract_leavers",
     "flowmpm_insert_arrivals", "flowmpm_set_mode_uniforms", "flowmpm_halo_words", "flowmpm_halo_pack",
     "flowmpm_halo_add", "flowmpm_find_leavers", "flowmpm_pack_leavers", "flowmpm_grid_sums",
-    "flowmpm_set_domain_particles",
+    "flowmpm_set_domain_particles", "flowmpm_get_allocation_count",
 )
 
 
@@ -170,6 +170,7 @@ def load():
         "flowmpm_grid_sums": ([vp, i64p], ctypes.c_int),
         "flowmpm_find_leavers": ([vp, ip, i32, vp], ctypes.c_int),
         "flowmpm_pack_leavers": ([vp, i64p, i32, vp, i64], ctypes.c_int),
+        "flowmpm_get_allocation_count": ([vp, i64p], ctypes.c_int),
     }
     for name, (argtypes, restype) in protos.items():
         fn = getattr(L, name)

@@ -74,13 +74,14 @@ struct flowmpm_sim {
     {
         return mpm::FixedGrid{reinterpret_cast<int *>(cell), mass_i, dirty, 1 | mass_bit(mass_i)};
     }
-    // a slab's boundary planes receive the neighbours' contributions too, which set no bits
     // Work items whose arena reaches the planes a halo exchange changes (local planes 0, 1,
-    // slab_nx, slab_nx + 1; an arena spans 8 tx - 2 .. 8 tx + 9): tile x index 0, and from
-    // (slab_nx - 2) / 8 on.
+    // slab_nx, slab_nx + 1).  The arena of tile column tx spans local planes
+    // kTX tx - kRim .. kTX tx + kTX + kRim - 1, so the boundary columns are those with
+    // kTX tx - kRim <= 1, i.e. tx <= (1 + kRim) / kTX, and those with kTX tx + kTX + kRim - 1 >= slab_nx,
+    // i.e. tx >= ceil((slab_nx - kTX - kRim + 1) / kTX) = (slab_nx - kRim) / kTX (rounded down, not below 0).
     mpm::StagePart stage_part(int part) const
     {
-        return mpm::StagePart{part, 0, std::max(cfg.slab_nx - 2, 0) / mpm::kTX};
+        return mpm::StagePart{part, (1 + mpm::kRim) / mpm::kTX, std::max(cfg.slab_nx - mpm::kRim, 0) / mpm::kTX};
     }
     mpm::TileRange tile_range() const
     {
@@ -93,6 +94,15 @@ struct flowmpm_sim {
     mpm::TiledState tiled{};     // bins, work items (FLOWMPM_ALGO_TILED)
 
     mpm::MigrationScratch migration{};   // device scratch of the leaver classification
+
+    // Staging of the read-backs and uploads: one device buffer and one pinned host buffer per handle,
+    // grown geometrically and freed in flowmpm_destroy, so that a renderer reading positions every
+    // frame allocates nothing after its first frame.
+    void *stage_dev = nullptr;
+    size_t stage_dev_bytes = 0;
+    void *stage_host = nullptr;
+    size_t stage_host_bytes = 0;
+    long long stage_allocations = 0;     // hipMalloc / hipHostMalloc calls made for the two buffers
 
     bool profiling = false;      // the launches being enqueued right now are timed
     int profile_stride = 0;      // 0 off, k: every k-th step of flowmpm_step
@@ -463,29 +473,79 @@ int alloc_store(flowmpm_sim *s, int which)
     return FLOWMPM_OK;
 }
 
+// The handle's device staging buffer, at least `bytes` large.  Growing it frees the old one, which is
+// safe here: every user synchronises the stream before it returns.
+int stage_device(flowmpm_sim *s, size_t bytes, void **out)
+{
+    if (s->stage_dev_bytes < bytes) {
+        const size_t want = (std::max(bytes, 2 * s->stage_dev_bytes) + 255) / 256 * 256;
+        HIP_TRY(s, hipStreamSynchronize(s->stream));
+        if (s->stage_dev) (void)hipFree(s->stage_dev);
+        s->stage_dev = nullptr;
+        s->stage_dev_bytes = 0;
+        HIP_TRY(s, hipMalloc(&s->stage_dev, want));
+        s->stage_dev_bytes = want;
+        s->stage_allocations += 1;
+    }
+    *out = s->stage_dev;
+    return FLOWMPM_OK;
+}
+
+// Transfers up to this size go through the handle's pinned host buffer (the per-frame reads of a
+// renderer: 262,144 positions are 3 MiB); larger ones (whole-store parity dumps) go straight to the
+// caller's memory.
+constexpr size_t kPinnedStageMax = (size_t)64 << 20;
+
+int stage_pinned(flowmpm_sim *s, size_t bytes, void **out)
+{
+    if (s->stage_host_bytes < bytes) {
+        const size_t want = std::min(kPinnedStageMax, (std::max(bytes, 2 * s->stage_host_bytes) + 4095) / 4096 * 4096);
+        HIP_TRY(s, hipStreamSynchronize(s->stream));
+        if (s->stage_host) (void)hipHostFree(s->stage_host);
+        s->stage_host = nullptr;
+        s->stage_host_bytes = 0;
+        HIP_TRY(s, hipHostMalloc(&s->stage_host, want, hipHostMallocDefault));
+        s->stage_host_bytes = want;
+        s->stage_allocations += 1;
+    }
+    *out = s->stage_host;
+    return FLOWMPM_OK;
+}
+
+// Device -> caller's host memory, then waits for the stream.
+int copy_out_and_wait(flowmpm_sim *s, void *host_dst, const void *dev_src, size_t bytes, const char *what)
+{
+    void *via = nullptr;
+    if (bytes <= kPinnedStageMax) {
+        int rc = stage_pinned(s, bytes, &via);
+        if (rc) return rc;
+    }
+    hipError_t e = hipMemcpyAsync(via ? via : host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    if (via) memcpy(host_dst, via, bytes);
+    return FLOWMPM_OK;
+}
+
 // Uploads `count` host records into slots [first_slot, first_slot + count).
 int upload_records(flowmpm_sim *s, const float *aos, const int32_t *ids, long long first_slot,
                    long long count)
 {
     if (count == 0) return FLOWMPM_OK;
-    float *d_aos = nullptr;
-    int *d_ids = nullptr;
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&d_aos), (size_t)count * 28 * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(d_aos, aos, (size_t)count * 28 * sizeof(float),
-                                  hipMemcpyHostToDevice, s->stream);
-    if (e == hipSuccess && ids) {
-        e = hipMalloc(reinterpret_cast<void **>(&d_ids), (size_t)count * sizeof(int));
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(d_ids, ids, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s->stream);
-    }
+    const size_t aos_bytes = (size_t)count * 28 * sizeof(float), id_bytes = ids ? (size_t)count * sizeof(int) : 0;
+    void *stage = nullptr;
+    int rc = stage_device(s, aos_bytes + id_bytes, &stage);
+    if (rc) return rc;
+    float *d_aos = static_cast<float *>(stage);
+    int *d_ids = ids ? reinterpret_cast<int *>(static_cast<char *>(stage) + aos_bytes) : nullptr;
+    hipError_t e = hipMemcpyAsync(d_aos, aos, aos_bytes, hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess && ids) e = hipMemcpyAsync(d_ids, ids, id_bytes, hipMemcpyHostToDevice, s->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(mpm::aos_to_soa_kernel, dim3(blocks_for(count, 256)), dim3(256), 0, s->stream,
                            d_aos, d_ids, s->store, first_slot, count);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-    (void)hipFree(d_aos);
-    if (d_ids) (void)hipFree(d_ids);
     if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
     return FLOWMPM_OK;
 }
@@ -604,6 +664,9 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
             HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->dirty), (size_t)s->tiled.n_tiles * sizeof(int)));
             HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
         }
+        // The leaver lists are sized once: a quarter of the slots may leave in one step before the
+        // lists have to grow (growing frees device memory, which waits for the device).
+        if (s->slab) s->migration.reserve = std::max<long long>(4096, s->capacity / 4);
         HIP_TRY(s, hipStreamSynchronize(s->stream));
         return FLOWMPM_OK;
     };
@@ -637,6 +700,8 @@ int flowmpm_destroy(flowmpm_sim *s)
     if (s->d_modes) (void)hipFree(s->d_modes);
     if (s->migration.counters) (void)hipFree(s->migration.counters);
     if (s->migration.lists) (void)hipFree(s->migration.lists);
+    if (s->stage_dev) (void)hipFree(s->stage_dev);
+    if (s->stage_host) (void)hipHostFree(s->stage_host);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return FLOWMPM_OK;
@@ -769,25 +834,23 @@ int flowmpm_download_particles(flowmpm_sim *s, float *aos, int32_t *ids, int64_t
     if (count) *count = total;
     if (!aos || capacity < total) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
     if (total == 0) return FLOWMPM_OK;
-    float *d_aos = nullptr;
-    int *d_ids = nullptr;
     const long long n = s->resident;
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&d_aos), (size_t)std::max<long long>(n, 1) * 28 * sizeof(float)));
-    hipError_t e = hipSuccess;
-    if (s->slab) e = hipMalloc(reinterpret_cast<void **>(&d_ids), (size_t)std::max<long long>(n, 1) * sizeof(int));
-    if (e == hipSuccess && n > 0) {
+    if (n > 0) {
+        const size_t aos_bytes = (size_t)n * 28 * sizeof(float), id_bytes = s->slab ? (size_t)n * sizeof(int) : 0;
+        void *stage = nullptr;
+        int rc = stage_device(s, aos_bytes + id_bytes, &stage);
+        if (rc) return rc;
+        float *d_aos = static_cast<float *>(stage);
+        int *d_ids = s->slab ? reinterpret_cast<int *>(static_cast<char *>(stage) + aos_bytes) : nullptr;
         hipLaunchKernelGGL(mpm::soa_to_aos_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->store,
                            n, d_aos, d_ids, s->slab ? 0 : 1);
-        e = hipGetLastError();
+        if ((rc = launch_check(s, "soa_to_aos"))) return rc;
+        if (s->slab && ids) {
+            hipError_t e = hipMemcpyAsync(ids, d_ids, id_bytes, hipMemcpyDeviceToHost, s->stream);
+            if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("download ids: ") + hipGetErrorString(e));
+        }
+        if ((rc = copy_out_and_wait(s, aos, d_aos, aos_bytes, "download"))) return rc;
     }
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(aos, d_aos, (size_t)n * 28 * sizeof(float), hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess && s->slab && ids)
-        e = hipMemcpyAsync(ids, d_ids, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-    (void)hipFree(d_aos);
-    if (d_ids) (void)hipFree(d_ids);
-    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("download: ") + hipGetErrorString(e));
     if (!s->slab && s->uploaded > s->resident)   // records beyond the live count are host-held
         memcpy(aos + s->resident * 28, s->shadow.data(), (size_t)(s->uploaded - s->resident) * 28 * sizeof(float));
     return FLOWMPM_OK;
@@ -830,17 +893,13 @@ int flowmpm_download_field(flowmpm_sim *s, int32_t field, float *out, int64_t ca
     const long long n = s->resident;
     if (!out || capacity < n) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
     if (n == 0) return FLOWMPM_OK;
-    float *d = nullptr;
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&d), (size_t)n * width * sizeof(float)));
+    void *stage = nullptr;
+    int rc = stage_device(s, (size_t)n * width * sizeof(float), &stage);
+    if (rc) return rc;
     hipLaunchKernelGGL(mpm::gather_field_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->store, n,
-                       slot, width, d);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(out, d, (size_t)n * width * sizeof(float), hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-    (void)hipFree(d);
-    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("download_field: ") + hipGetErrorString(e));
-    return FLOWMPM_OK;
+                       slot, width, static_cast<float *>(stage));
+    if ((rc = launch_check(s, "gather_field"))) return rc;
+    return copy_out_and_wait(s, out, stage, (size_t)n * width * sizeof(float), "download_field");
 }
 
 int flowmpm_get_local_grid(flowmpm_sim *s, int32_t *x_first, int32_t *x_planes)
@@ -856,26 +915,20 @@ int flowmpm_download_grid_i32(flowmpm_sim *s, int32_t *out, int64_t capacity_cel
     CHECK_SIM(s);
     if (!out || capacity_cells < s->local_cells) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
     // The device keeps the mass words apart; hosts get the reference's {x, y, z, mass} records.
-    int4 *tmp = nullptr;
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)s->local_cells * sizeof(int4)));
+    void *stage = nullptr;
+    int rc = stage_device(s, (size_t)s->local_cells * sizeof(int4), &stage);
+    if (rc) return rc;
     hipLaunchKernelGGL(mpm::assemble_cells_kernel, dim3(blocks_for(s->local_cells, 256)), dim3(256), 0, s->stream,
-                       s->cell, s->mass_i, tmp, s->local_cells);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(out, tmp, (size_t)s->local_cells * sizeof(int4), hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("download_grid_i32: ") + hipGetErrorString(e));
-    return FLOWMPM_OK;
+                       s->cell, s->mass_i, static_cast<int4 *>(stage), s->local_cells);
+    if ((rc = launch_check(s, "assemble_cells"))) return rc;
+    return copy_out_and_wait(s, out, stage, (size_t)s->local_cells * sizeof(int4), "download_grid_i32");
 }
 
 int flowmpm_download_grid_f32(flowmpm_sim *s, float *out, int64_t capacity_cells)
 {
     CHECK_SIM(s);
     if (!out || capacity_cells < s->local_cells) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
-    HIP_TRY(s, hipMemcpyAsync(out, s->cellf, (size_t)s->local_cells * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(s, hipStreamSynchronize(s->stream));
-    return FLOWMPM_OK;
+    return copy_out_and_wait(s, out, s->cellf, (size_t)s->local_cells * sizeof(float4), "download_grid_f32");
 }
 
 int flowmpm_set_profiling(flowmpm_sim *s, int32_t every_nth_step)
@@ -919,6 +972,13 @@ int flowmpm_reset_timings(flowmpm_sim *s)
     if (is_tiled(s))
         HIP_TRY(s, hipMemsetAsync(&s->tiled.ctl->rebins, 0, offsetof(mpm::RebinCtl, t_start) - offsetof(mpm::RebinCtl, rebins),
                                   s->stream));
+    return FLOWMPM_OK;
+}
+
+int flowmpm_get_allocation_count(flowmpm_sim *s, int64_t *count)
+{
+    if (!s || !count) return fail(s, FLOWMPM_ERR_INVALID, "null argument");
+    *count = s->stage_allocations + s->migration.allocations;
     return FLOWMPM_OK;
 }
 
@@ -981,19 +1041,15 @@ int flowmpm_grid_sums(flowmpm_sim *s, int64_t *sums)
     const long long plane = (long long)s->cfg.grid_y * s->cfg.grid_z;
     const long long first = s->slab ? plane : 0;                       // skip the low halo plane
     const long long cells = s->slab ? (long long)s->cfg.slab_nx * plane : s->local_cells;
-    unsigned long long *d = nullptr;
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&d), 4 * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), s->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(mpm::grid_sums_kernel, dim3(1024), dim3(256), 0, s->stream, s->cell + first,
-                           s->mass_i + first, cells, d);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(sums, d, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-    (void)hipFree(d);
-    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("grid_sums: ") + hipGetErrorString(e));
-    return FLOWMPM_OK;
+    void *stage = nullptr;
+    int rc = stage_device(s, 4 * sizeof(unsigned long long), &stage);
+    if (rc) return rc;
+    unsigned long long *d = static_cast<unsigned long long *>(stage);
+    HIP_TRY(s, hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), s->stream));
+    hipLaunchKernelGGL(mpm::grid_sums_kernel, dim3(1024), dim3(256), 0, s->stream, s->cell + first,
+                       s->mass_i + first, cells, d);
+    if ((rc = launch_check(s, "grid_sums"))) return rc;
+    return copy_out_and_wait(s, sums, d, 4 * sizeof(int64_t), "grid_sums");
 }
 
 // First cell and cell count of the two adjacent boundary planes of one side.

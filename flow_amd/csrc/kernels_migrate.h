@@ -176,6 +176,8 @@ struct MigrationScratch {
     long long list_cap = 0;
     RankTable table{};            // of the classification in flight
     long long classified = -1;    // resident count it ran on (-1: none in flight)
+    long long reserve = 4096;     // list entries allocated at the first classification
+    long long allocations = 0;    // hipMalloc calls made for the counters and lists
 };
 
 inline int migration_reserve(MigrationScratch &M, long long want, std::string *msg)
@@ -186,6 +188,7 @@ inline int migration_reserve(MigrationScratch &M, long long want, std::string *m
             *msg = std::string("hipMalloc counters: ") + hipGetErrorString(e);
             return 1;
         }
+        M.allocations += 1;
         if ((e = hipMemset(M.counters, 0, kCounterWords * sizeof(int))) != hipSuccess) {
             *msg = std::string("hipMemset counters: ") + hipGetErrorString(e);
             return 1;
@@ -199,6 +202,7 @@ inline int migration_reserve(MigrationScratch &M, long long want, std::string *m
             *msg = std::string("hipMalloc leaver lists: ") + hipGetErrorString(e);
             return 1;
         }
+        M.allocations += 1;
         M.list_cap = want;
     }
     return 0;
@@ -221,8 +225,8 @@ inline int find_leavers(MigrationScratch &M, StoreSel st, long long n, int x0, i
         *msg = "no classification of these particles is in flight";
         return 3;
     }
-    // room for 1/64 of the particles to leave in one step; pack_leavers doubles it when that is not enough
-    if (migration_reserve(M, std::max<long long>(M.list_cap, std::max<long long>(4096, n / 64)), msg)) return 1;
+    // sized once (MigrationScratch::reserve); pack_leavers grows it when a step has more leavers than that
+    if (migration_reserve(M, std::max<long long>(M.list_cap, M.reserve), msg)) return 1;
     M.table = RankTable{};
     M.table.n = n_ranks;
     for (int r = 0; r <= n_ranks; r++) M.table.starts[r] = plane_starts[r];

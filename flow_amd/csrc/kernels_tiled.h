@@ -1350,6 +1350,7 @@ constexpr int kStragglerBlocks = 1024;
 inline int launch_p2g1_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream,
                              hipEvent_t ev_start, hipEvent_t ev_stop)
 {
+    T.listed = -1;      // this stage overwrites the one straggler list: a momentum pass's list is gone
     FLOWMPM_TILED_STAGE(p2g1_tiled_kernel, straggler_p2g_kernel<0>, g);
 }
 
@@ -1365,6 +1366,7 @@ inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedG
                                  hipEvent_t ev_start, hipEvent_t ev_stop, int keep_lo = -2147483647 - 1,
                                  int keep_hi = 2147483647)
 {
+    T.listed = -1;      // this stage overwrites the one straggler list: a momentum pass's list is gone
     TiledWork w = tiled_work(T, st, n);
     w.keep_lo = keep_lo;
     w.keep_hi = keep_hi;

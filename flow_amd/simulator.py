@@ -162,6 +162,12 @@ class Handle:
         """0 / False: off; 1 / True: every launch; k: the launches of every k-th step()."""
         self._chk(self.L.flowmpm_set_profiling(self._h, int(every_nth_step)))
 
+    def allocation_count(self):
+        """Device / pinned allocations the handle has made for staging since it was created."""
+        out = ctypes.c_int64(0)
+        self._chk(self.L.flowmpm_get_allocation_count(self._h, ctypes.byref(out)))
+        return out.value
+
     def reset_timings(self):
         self._chk(self.L.flowmpm_reset_timings(self._h))
 

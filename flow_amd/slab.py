@@ -193,6 +193,9 @@ class GpuSlabBackend:
     def new_record_buffer(self, count):
         return torch.empty((count, RECORD_WORDS), dtype=torch.float32, device=self.torch_device)
 
+    def leaver_capacity(self):
+        return int(self._leavers.shape[0])
+
     def grid_sums(self):
         return self.handle.grid_sums()
 
@@ -242,6 +245,12 @@ class SlabSimulation:
         self.early_counts = (self.transport is not None and not self.transport.stage and backend is None
                              and os.environ.get("FLOWMPM_SLAB_EARLY_COUNTS", "1") != "0")
         self.migrated_out = 0       # particles this rank has sent away so far
+        self.max_hop = 0            # farthest destination so far, in slabs (1 = a neighbour)
+        # What every rank knows about every rank, so that an overflow anywhere is seen everywhere:
+        # [leaver-buffer records, max_particles] per rank (gathered once) and the resident count per
+        # rank (gathered once, then kept up to date from the count matrices, which every rank sees).
+        self._limits = None
+        self._residents = None
         self._send = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
         self._recv = {(side, m): b.new_halo_buffer(m) for side in ("low", "high") for m in masks}
 
@@ -259,6 +268,7 @@ class SlabSimulation:
         rank that owns floor(x), then uploaded there with its global id."""
         records = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, _lib.PARTICLE_STRIDE)
         ids = np.ascontiguousarray(ids, dtype=np.int32)
+        self._residents = None      # a new particle set: the bookkeeping starts over
         # uniforms.numParticles of the whole domain (mlsMpmSimulator.js:2513-2522): g2p's
         # hide-percentage branch divides the particle id by it
         total = records.shape[0]
@@ -395,7 +405,10 @@ class SlabSimulation:
         else:
             matrix = self._all_gather_counts(counts_dev, self._comm_device())
         counts = matrix[self.rank]
+        self._check_capacities(matrix)
         self.migrated_out += int(counts.sum())
+        for peer in np.nonzero(counts)[0]:
+            self.max_hop = max(self.max_hop, abs(int(peer) - self.rank))
         packed = b.pack_leavers(counts)
         if not matrix.any():
             return
@@ -414,6 +427,34 @@ class SlabSimulation:
         self.transport.exchange(sends, recvs)
         for buf in inbox:
             b.insert_arrivals(buf)
+
+    def _check_capacities(self, matrix):
+        """Every rank holds the whole count matrix, so every rank can see whether ANY rank is about to
+        overflow its leaver buffer (its row sum) or its particle store (what it keeps plus its column
+        sum) -- and all of them raise together, before any point-to-point transfer is posted.  A rank
+        that failed alone would leave its neighbours waiting for its records for ever."""
+        if self._limits is None or self._residents is None:
+            b = self.backend
+            mine = np.array([getattr(b, "leaver_capacity", lambda: 2 ** 62)(),
+                             getattr(b, "max_particles", 2 ** 62) or 2 ** 62, b.resident()], dtype=np.int64)
+            dev = self._comm_device()
+            out = torch.empty(self.world * 3, dtype=torch.int64, device=dev)
+            self.dist.all_gather_into_tensor(out, torch.from_numpy(mine).to(dev))
+            table = out.cpu().numpy().reshape(self.world, 3)
+            self._limits, self._residents = table[:, 0:2].copy(), table[:, 2].copy()
+        leaving, arriving = matrix.sum(axis=1), matrix.sum(axis=0)
+        after = self._residents - leaving + arriving
+        problems = []
+        for r in range(self.world):
+            if leaving[r] > self._limits[r, 0]:
+                problems.append("rank %d sends %d particles away in one step but its leaver buffer holds %d"
+                                % (r, leaving[r], self._limits[r, 0]))
+            if after[r] > self._limits[r, 1]:
+                problems.append("rank %d would hold %d particles but was created for %d"
+                                % (r, after[r], self._limits[r, 1]))
+        if problems:
+            raise _lib.FlowMpmError(_lib.ERR_CAPACITY, "slab migration: " + "; ".join(problems))
+        self._residents = after
 
     def step(self):
         b = self.backend

@@ -277,6 +277,14 @@ int flowmpm_set_profiling(flowmpm_sim *sim, int32_t every_nth_step);
 int flowmpm_get_timings(flowmpm_sim *sim, flowmpm_timings *out);
 int flowmpm_reset_timings(flowmpm_sim *sim);
 
+/* The read-backs above replace the per-frame buffer binding of the reference's renderers
+ * (src/mls-mpm/particleRenderer.js:126-133, src/mls-mpm/pointRenderer.js:17-19), so they are called
+ * every frame: each handle stages them through one device buffer and one pinned host buffer that
+ * grow geometrically and live until flowmpm_destroy.  `count` receives the number of device / pinned
+ * allocations the handle has made for staging (and for the leaver lists of a slab) since
+ * flowmpm_create; it stops growing once the buffers have reached the size of the largest transfer. */
+int flowmpm_get_allocation_count(flowmpm_sim *sim, int64_t *count);
+
 /* ---- Slab decomposition (no reference counterpart: the reference is single-GPU).
  * The caller owns the transport (RCCL through torch.distributed) and its device buffers;
  * these are the device-side pieces. ---- */

@@ -201,6 +201,11 @@ def main():
     ap.add_argument("--balanced", action="store_true")
     ap.add_argument("--algorithm", choices=("tiled", "scatter"), default="tiled")
     ap.add_argument("--mode-case", default=None, help="a case name of tests/mode_cases.py (grid 128,64,64)")
+    ap.add_argument("--dt", type=float, default=DEFAULT_UNIFORMS["dt"],
+                    help="a large dt makes particles jump over whole slabs in one step")
+    ap.add_argument("--leaver-capacity-of-rank1", type=int, default=-1,
+                    help="oracle backend: rank 1 claims a leaver buffer of this many records; the run must then "
+                         "end with the capacity error on EVERY rank (marker files), not with a hang")
     args = ap.parse_args()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -222,6 +227,8 @@ def main():
     x0, nx = starts[rank], starts[rank + 1] - starts[rank]
     if args.backend == "oracle":
         backend = OracleSlabBackend(grid, x0, nx)
+        if args.leaver_capacity_of_rank1 >= 0 and rank == 1:
+            backend.leaver_capacity = lambda: args.leaver_capacity_of_rank1
         sim = SlabSimulation(grid, starts, rank, world, dist=dist, backend=backend)
     else:
         algo = _lib.ALGO_TILED if args.algorithm == "tiled" else _lib.ALGO_SCATTER
@@ -230,10 +237,17 @@ def main():
     sim.scatter_initial_particles(rec[lo:hi], np.arange(lo, hi, dtype=np.int32))
     if mode_fields is not None:
         sim.set_mode_uniforms(mode_cases.fill(_lib.ModeUniforms, mode_fields))
-    for k in range(args.steps):
-        sim.set_uniforms(**dict(DEFAULT_UNIFORMS, time=0.25 * k, **mode_uni))
-        sim.step()
-    sim.synchronize()
+    try:
+        for k in range(args.steps):
+            sim.set_uniforms(**dict(DEFAULT_UNIFORMS, dt=args.dt, time=0.25 * k, **mode_uni))
+            sim.step()
+        sim.synchronize()
+    except _lib.FlowMpmError as exc:
+        if args.leaver_capacity_of_rank1 < 0 or exc.code != _lib.ERR_CAPACITY:
+            raise
+        with open(os.path.join(args.out, "rank%d.capacity" % rank), "w") as f:
+            f.write(str(exc))
+        return      # no collective may follow: every rank left the step at the same point
     totals = sim.conservation()
     out_rec, out_ids = sim.download()
     if args.backend == "oracle":
@@ -243,7 +257,7 @@ def main():
         cell = sim.backend.handle.download_grid_i32()[per:(nx + 1) * per]
         cellf = sim.backend.handle.download_grid_f32()[per:(nx + 1) * per]
     np.savez(os.path.join(args.out, "rank%d.npz" % rank), rec=out_rec, ids=out_ids, cell=cell, cellf=cellf,
-             starts=np.asarray(starts), totals=totals)
+             starts=np.asarray(starts), totals=totals, max_hop=sim.max_hop)
     sim.close()
     dist.barrier()
     dist.destroy_process_group()

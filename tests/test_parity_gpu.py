@@ -646,3 +646,59 @@ def test_dam_break_configuration_with_the_scripted_mouse_ray():
     particles = outs[0][1]
     del outs
     assert _grid_mass_of(grid, particles, uni) == _truncated_weight_sum(particles[:, 0:3])
+
+
+def test_a_stage_between_the_momentum_pass_and_g2p_does_not_lose_the_stragglers():
+    """g2p reuses the straggler list of the momentum pass of the same step.  Any tiled stage run in
+    between overwrites that one list; g2p must then list its stragglers itself instead of skipping
+    them.  Drifted particles (a re-bin only every 50 steps) make sure there are stragglers."""
+    grid, n = (48, 32, 32), 40000
+    rec = moving_particles(n, grid, seed=31, vel=2.5)
+    tiled = _handle(grid, rec, _lib.ALGO_TILED, rebin_interval=50)
+    scatter = _handle(grid, rec, _lib.ALGO_SCATTER)
+    tiled.step(6, 0.0)
+    scatter.step(6, 0.0)
+    assert tiled.timings()["rebin"]["stragglers"] > 0
+    for k in (_lib.KERNEL_CLEAR_FIXED_GRID, _lib.KERNEL_P2G_MASS, _lib.KERNEL_P2G_MOMENTUM, _lib.KERNEL_UPDATE_GRID,
+              # the float grid is complete; these two touch the fixed-point grid and the straggler list only
+              _lib.KERNEL_CLEAR_FIXED_GRID, _lib.KERNEL_P2G_MASS,
+              _lib.KERNEL_G2P):
+        tiled.run_kernel(k)
+    scatter.step(1, 0.0)
+    assert_bits_equal(tiled.download_particles(), scatter.download_particles(), "particles after the odd order")
+    # the same with p2g1 in between
+    for k in (_lib.KERNEL_CLEAR_GRID, _lib.KERNEL_P2G_MASS, _lib.KERNEL_P2G_MOMENTUM, _lib.KERNEL_UPDATE_GRID,
+              _lib.KERNEL_CLEAR_FIXED_GRID, _lib.KERNEL_P2G1, _lib.KERNEL_G2P):
+        tiled.run_kernel(k)
+    scatter.step(1, 0.0)
+    assert_bits_equal(tiled.download_particles(), scatter.download_particles(), "particles, p2g1 in between")
+    tiled.close()
+    scatter.close()
+
+
+def test_per_frame_reads_allocate_nothing_after_the_first():
+    """getPositions / getDensities / getColors replace the reference renderers' per-frame buffer binding
+    (particleRenderer.js:126-133): a thousand frames of reads make no device or pinned allocation
+    beyond those of the first frame, and keep returning the right values."""
+    grid, n = (32, 16, 16), 5000
+    rec = moving_particles(n, grid, seed=32)
+    h = _handle(grid, rec, _lib.ALGO_TILED)
+    h.step(1, 0.0)
+    for field in (_lib.FIELD_POSITION, _lib.FIELD_DENSITY, _lib.FIELD_COLOR):
+        h.download_field(field)
+    h.download_particles()
+    h.download_grid_i32()
+    h.grid_sums()
+    before = h.allocation_count()
+    assert 1 <= before <= 8
+    for frame in range(1000):
+        h.step(1, 0.0)
+        pos = h.download_field(_lib.FIELD_POSITION)
+        if frame % 250 == 0:
+            h.download_field(_lib.FIELD_DENSITY)
+            h.download_field(_lib.FIELD_COLOR)
+            assert_bits_equal(pos, h.download_particles()[:, 0:3], "positions at frame %d" % frame)
+            h.download_grid_i32()
+            h.grid_sums()
+    assert h.allocation_count() == before
+    h.close()

@@ -23,20 +23,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(world, out, *extra):
+def _launch(world, out, *extra, timeout=600):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "slab_worker.py"), "--out", str(out)] + list(extra)
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-def _reference_run(oracle_binding, grid, n, steps, vel):
+def _reference_run(oracle_binding, grid, n, steps, vel, dt=DEFAULT_UNIFORMS["dt"]):
     rec = moving_particles(n, grid, seed=41, vel=vel)
     orc = oracle_binding.Oracle(grid)
     for k in range(steps):
-        orc.step(rec, oracle_binding.make_uniforms(grid, n, **dict(DEFAULT_UNIFORMS, time=0.25 * k)))
+        orc.step(rec, oracle_binding.make_uniforms(grid, n, **dict(DEFAULT_UNIFORMS, dt=dt, time=0.25 * k)))
     return rec, orc
 
 
@@ -80,6 +80,33 @@ def test_slab_protocol_balanced_boundaries(oracle_binding, tmp_path):
             "--steps", str(steps), "--vel", str(vel), "--balanced")
     rec, orc = _reference_run(oracle_binding, grid, n, steps, vel)
     _check_against_single_domain(tmp_path, 2, rec, orc, grid)
+
+
+def test_eight_slabs_of_uneven_width_on_cpu_match_single_domain(oracle_binding, tmp_path):
+    """The 8-way decomposition: eight ranks over gloo, slab boundaries cut at particle quantiles (widths
+    that are no multiple of anything), and a time step large enough that particles cross several
+    slabs in one step, so leavers go to owners that are not neighbours."""
+    grid, n, steps, vel, dt = (61, 10, 10), 4000, 8, 3.0, 1.0
+    _launch(8, tmp_path, "--backend", "oracle", "--grid", "61,10,10", "--particles", str(n),
+            "--steps", str(steps), "--vel", str(vel), "--dt", str(dt), "--balanced")
+    rec, orc = _reference_run(oracle_binding, grid, n, steps, vel, dt=dt)
+    moved = _check_against_single_domain(tmp_path, 8, rec, orc, grid)
+    assert moved > 0
+    hops = [int(np.load(os.path.join(tmp_path, "rank%d.npz" % r))["max_hop"]) for r in range(8)]
+    assert max(hops) >= 2, "no particle jumped over a whole slab: %r" % hops
+    widths = np.diff(np.load(os.path.join(tmp_path, "rank0.npz"))["starts"])
+    assert len(set(widths.tolist())) > 2, "the cut should be uneven: %r" % widths
+
+
+def test_an_overflow_on_one_rank_ends_every_rank(tmp_path):
+    """A leaver buffer too small on rank 1 only: every rank sees it in the count matrix and raises the
+    capacity error at the same point, instead of rank 1 failing alone while its neighbours wait for
+    its records for ever."""
+    _launch(3, tmp_path, "--backend", "oracle", "--grid", "24,12,12", "--particles", "2500", "--steps", "12",
+            "--vel", "3.0", "--leaver-capacity-of-rank1", "0", timeout=180)
+    for r in range(3):
+        with open(os.path.join(tmp_path, "rank%d.capacity" % r)) as f:
+            assert "rank 1 sends" in f.read()
 
 
 def _mode_reference_run(oracle_binding, case_name, n, steps, vel):
@@ -228,3 +255,98 @@ def test_two_rank_rehearsal_with_mode_forces(oracle_binding, tmp_path, case_name
     rec, orc = _mode_reference_run(oracle_binding, case_name, n, steps, vel)
     moved = _check_against_single_domain(tmp_path, 2, rec, orc, (128, 64, 64))
     assert moved > 0
+
+
+@pytest.mark.gpu
+def test_eight_slabs_in_one_process_match_single_domain(oracle_binding):
+    """Eight slab handles of uneven width on one GPU, the tiled algorithm's own stages (mass pass,
+    momentum pass, packed halo pairs), leavers handed to whichever slab owns them -- with a time step
+    large enough that some jump over whole slabs -- against the single-domain oracle, bit for bit,
+    plus the conservation sums."""
+    import torch
+    from flow_amd.slab import SlabSimulation
+
+    grid, n, steps, dt = (142, 16, 16), 30000, 8, 1.0
+    starts = [0, 37, 48, 57, 66, 74, 83, 95, 142]       # a balanced cut's shape: wide ends, thin middle
+    world = len(starts) - 1
+    rec = moving_particles(n, grid, seed=43, vel=3.0)
+    sims = [SlabSimulation(grid, starts, r, world, max_particles=n, device=0, algorithm=_lib.ALGO_TILED,
+                           rebin_interval=3) for r in range(world)]
+    dest = np.searchsorted(np.asarray(starts), np.floor(rec[:, 0]).astype(int), side="right") - 1
+    for r, s in enumerate(sims):
+        rows = np.nonzero(dest == r)[0]
+        s.backend.upload(rec[rows], rows.astype(np.int32))
+
+    def exchange(mask):
+        packed = [(s.backend.new_halo_buffer(mask), s.backend.new_halo_buffer(mask)) for s in sims]
+        for r, s in enumerate(sims):
+            if r > 0:
+                s.backend.halo_pack(_lib.SIDE_LOW, mask, packed[r][0])
+            if r < world - 1:
+                s.backend.halo_pack(_lib.SIDE_HIGH, mask, packed[r][1])
+        torch.cuda.synchronize()
+        for r, s in enumerate(sims):
+            if r > 0:
+                s.backend.halo_add(_lib.SIDE_LOW, mask, packed[r - 1][1])
+            if r < world - 1:
+                s.backend.halo_add(_lib.SIDE_HIGH, mask, packed[r + 1][0])
+        torch.cuda.synchronize()
+
+    moved, far = 0, 0
+    for k in range(steps):
+        for s in sims:
+            s.set_uniforms(**dict(DEFAULT_UNIFORMS, dt=dt, time=0.25 * k))
+            s.backend.run_kernel(_lib.KERNEL_CLEAR_FIXED_GRID)
+            s.backend.run_kernel(_lib.KERNEL_P2G_MASS)
+        exchange(_lib.COMP_MASS)
+        for s in sims:
+            s.backend.run_kernel(_lib.KERNEL_P2G_MOMENTUM)
+        exchange(_lib.COMP_MOMENTUM)
+        if k == steps - 1:
+            sums = sum(s.backend.grid_sums().astype(np.int64) for s in sims)
+        for s in sims:
+            s.backend.run_kernel(_lib.KERNEL_UPDATE_GRID)
+            s.backend.run_kernel(_lib.KERNEL_G2P)
+        out = [s.backend.extract_leavers(starts) for s in sims]
+        torch.cuda.synchronize()
+        for r, (counts, packed) in enumerate(out):
+            assert counts[r] == 0
+            offs = np.concatenate([[0], np.cumsum(counts)])
+            for peer in np.nonzero(counts)[0]:
+                moved += int(counts[peer])
+                far += int(counts[peer]) if abs(int(peer) - r) >= 2 else 0
+                sims[peer].backend.insert_arrivals(packed[int(offs[peer]):int(offs[peer + 1])].clone())
+        torch.cuda.synchronize()
+    assert moved > 0 and far > 0, "the case must send particles past a neighbour (%d moved, %d far)" % (moved, far)
+
+    want = rec.copy()
+    orc = oracle_binding.Oracle(grid, threads=8)
+    for k in range(steps):
+        orc.step(want, oracle_binding.make_uniforms(grid, n, **dict(DEFAULT_UNIFORMS, dt=dt, time=0.25 * k)))
+    assert np.array_equal(sums, orc.cell.astype(np.int64).sum(axis=0)), "conservation sums over the 8 slabs"
+    per = grid[1] * grid[2]
+    total = 0
+    for r, s in enumerate(sims):
+        got, ids = s.download()
+        total += got.shape[0]
+        assert_bits_equal(got, want[ids], "slab %d particles" % r)
+        x0, x1 = starts[r], starts[r + 1]
+        cell = s.backend.handle.download_grid_i32()[per:(x1 - x0 + 1) * per]
+        assert np.array_equal(cell, orc.cell[x0 * per:x1 * per]), "slab %d grid" % r
+        s.close()
+    assert total == n
+
+
+@pytest.mark.gpu
+def test_eight_rank_rehearsal_on_one_gpu(oracle_binding, tmp_path):
+    """Eight processes on cuda:0 over gloo: SlabSimulation.step() exactly as the 8-GPU benchmark runs it
+    (split mass pass, interior / boundary launches, posted halo exchanges, migration to any owner),
+    uneven slab widths from the balanced cut, particles that jump over whole slabs."""
+    grid, n, steps, vel, dt = (150, 16, 16), 24000, 8, 3.0, 1.0
+    _launch(8, tmp_path, "--backend", "gpu", "--grid", "%d,%d,%d" % grid, "--particles", str(n),
+            "--steps", str(steps), "--vel", str(vel), "--dt", str(dt), "--balanced")
+    rec, orc = _reference_run(oracle_binding, grid, n, steps, vel, dt=dt)
+    moved = _check_against_single_domain(tmp_path, 8, rec, orc, grid)
+    assert moved > 0
+    hops = [int(np.load(os.path.join(tmp_path, "rank%d.npz" % r))["max_hop"]) for r in range(8)]
+    assert max(hops) >= 2, "no particle jumped over a whole slab: %r" % hops
