@@ -7,7 +7,7 @@
 // also writes, per frame, the packed mode uniforms plus {dt, gridMode, frontGravityMode}
 // (<out>.modes, <out>.frames.json) and getColors() after the last frame (<out>.colors).  A schedule
 // entry [mode, frames, "image.ppm"] hands that image to toggleGridMode (modes 1, 2, 7) and writes
-// getColors() right after the toggle to <out>.colors.<entry index>.
+// getColors() after that entry's frames to <out>.colors.<entry index>.
 const fs = require('fs');
 const { MlsMpmSimulator, Conf } = require('./index');
 
@@ -27,8 +27,7 @@ const { MlsMpmSimulator, Conf } = require('./index');
         let entry = 0;
         for (const [mode, count, image] of JSON.parse(schedule)) {
             await sim.toggleGridMode(mode, image);
-            if (image) fs.writeFileSync(out + '.colors.' + entry, Buffer.from(sim.getColors().buffer));
-            entry++;
+
             for (let k = 0; k < count; k++, f++) {
                 now += 16;
                 await sim.update(1 / 30, 0.5 * f);
@@ -36,6 +35,8 @@ const { MlsMpmSimulator, Conf } = require('./index');
                 info.push({ dt: sim.uniforms.dt.value, gridMode: sim.uniforms.gridMode.value,
                     frontGravityMode: sim.uniforms.frontGravityMode.value, time: sim.uniforms.time.value });
             }
+            if (image) fs.writeFileSync(out + '.colors.' + entry, Buffer.from(sim.getColors().buffer));
+            entry++;
         }
         fs.writeFileSync(out + '.modes', Buffer.concat(packs));
         fs.writeFileSync(out + '.frames.json', JSON.stringify(info));

@@ -223,7 +223,6 @@ def test_simulator_class_image_modes(oracle_binding, tmp_path):
         fields = dict(mode_cases._BASE, grid_noise_strength=0.5)        # conf.gridNoiseStrength, src/conf.js:15
         if pixels is not None:
             fields.update(helpers.reference_image_grid(pixels.shape[1], pixels.shape[0], conf.particles))
-            helpers.assert_image_mode_colors(sim.getColors(), pixels, mode, conf.particles)
         m = mode_cases.fill(ob.ModeUniforms, fields)
         for _ in range(frames):
             elapsed += 0.016
@@ -232,6 +231,8 @@ def test_simulator_class_image_modes(oracle_binding, tmp_path):
                                  rest_density=conf.restDensity, dynamic_viscosity=0.1, noise=1.0,
                                  time=np.float32(elapsed), grid_mode=1 if pixels is not None else 0)
             orc.step_modes(want, u, m)
+        if pixels is not None:      # numParticles is set by the first update() (SIM:2513-2522)
+            helpers.assert_image_mode_colors(sim.getColors(), pixels, mode, conf.particles)
     got = sim.readAoS()
     assert_bits_equal(got[:conf.particles, :24], want[:conf.particles, :24], "particles after the image modes")
     # the grid attraction has really acted: the same frames without the toggles end elsewhere

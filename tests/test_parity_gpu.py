@@ -648,17 +648,19 @@ def test_dam_break_configuration_with_the_scripted_mouse_ray():
     assert _grid_mass_of(grid, particles, uni) == _truncated_weight_sum(particles[:, 0:3])
 
 
-def test_a_stage_between_the_momentum_pass_and_g2p_does_not_lose_the_stragglers():
+def test_a_stage_between_the_momentum_pass_and_g2p_does_not_lose_the_stragglers(monkeypatch):
     """g2p reuses the straggler list of the momentum pass of the same step.  Any tiled stage run in
     between overwrites that one list; g2p must then list its stragglers itself instead of skipping
-    them.  Drifted particles (a re-bin only every 50 steps) make sure there are stragglers."""
-    grid, n = (48, 32, 32), 40000
-    rec = moving_particles(n, grid, seed=31, vel=2.5)
-    tiled = _handle(grid, rec, _lib.ALGO_TILED, rebin_interval=50)
+    them.  No re-bin after the first (drift rule off) makes sure there are stragglers."""
+    monkeypatch.setenv("FLOWMPM_DRIFT_DIVISOR", "0")
+    grid, n = (40, 24, 16), 6000
+    rec = moving_particles(n, grid, seed=77, vel=3.0)
+    tiled = _handle(grid, rec, _lib.ALGO_TILED, rebin_interval=100000)
     scatter = _handle(grid, rec, _lib.ALGO_SCATTER)
-    tiled.step(6, 0.0)
-    scatter.step(6, 0.0)
-    assert tiled.timings()["rebin"]["stragglers"] > 0
+    tiled.step(40, 0.0)
+    scatter.step(40, 0.0)
+    before = tiled.timings()["rebin"]["stragglers"]
+    assert before > 0
     for k in (_lib.KERNEL_CLEAR_FIXED_GRID, _lib.KERNEL_P2G_MASS, _lib.KERNEL_P2G_MOMENTUM, _lib.KERNEL_UPDATE_GRID,
               # the float grid is complete; these two touch the fixed-point grid and the straggler list only
               _lib.KERNEL_CLEAR_FIXED_GRID, _lib.KERNEL_P2G_MASS,
@@ -672,6 +674,7 @@ def test_a_stage_between_the_momentum_pass_and_g2p_does_not_lose_the_stragglers(
         tiled.run_kernel(k)
     scatter.step(1, 0.0)
     assert_bits_equal(tiled.download_particles(), scatter.download_particles(), "particles, p2g1 in between")
+    assert tiled.timings()["rebin"]["stragglers"] > before, "the two odd steps had no stragglers to lose"
     tiled.close()
     scatter.close()
 
