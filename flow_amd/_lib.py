@@ -47,6 +47,7 @@ EXPORTS = (
     "flowmpm_insert_arrivals", "flowmpm_set_mode_uniforms", "flowmpm_halo_words", "flowmpm_halo_pack",
     "flowmpm_halo_add", "flowmpm_find_leavers", "flowmpm_pack_leavers", "flowmpm_grid_sums",
     "flowmpm_set_domain_particles", "flowmpm_get_allocation_count",
+    "flowmpm_download_field_static",
 )
 
 
@@ -171,6 +172,7 @@ def load():
         "flowmpm_find_leavers": ([vp, ip, i32, vp], ctypes.c_int),
         "flowmpm_pack_leavers": ([vp, i64p, i32, vp, i64], ctypes.c_int),
         "flowmpm_get_allocation_count": ([vp, i64p], ctypes.c_int),
+        "flowmpm_download_field_static": ([vp, i32, fp, i64], ctypes.c_int),
     }
     for name, (argtypes, restype) in protos.items():
         fn = getattr(L, name)

@@ -15,15 +15,46 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstddef>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "kernels_scatter.h"
 #include "kernels_tiled.h"
 
+// ---- staging of flowmpm_download_field_static ------------------------------------------------
+// One array per GPU the library runs on, held until the process ends: the id-ordered values of one
+// particle field for at most kStaticFieldParticles particles (3 MiB).  In host code `scratch` is only
+// a stand-in for the symbol, never a device address: the address on a device comes from
+// hipGetSymbolAddress with that device current (scratch_setup, called by flowmpm_create), and host
+// code uses that pointer wherever it needs the array's memory.
+constexpr long long kStaticFieldParticles = 262144;          // conf.maxParticles, src/conf.js:8
+static __device__ __align__(256) float scratch[kStaticFieldParticles * 3];
+
 namespace {
 
 thread_local std::string g_last_error;
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+float *g_scratch_ptr[kMaxDevices] = {};       // per device: where that device's copy of `scratch` lives
+
+// With `device` current.  Returns hipSuccess and the device's address of `scratch`.
+hipError_t scratch_setup(int device, float **out)
+{
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = static_cast<float *>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 struct EventPair {
     hipEvent_t start, stop;
@@ -103,6 +134,7 @@ struct flowmpm_sim {
     void *stage_host = nullptr;
     size_t stage_host_bytes = 0;
     long long stage_allocations = 0;     // hipMalloc / hipHostMalloc calls made for the two buffers
+    float *static_field = nullptr;       // this device's `scratch` array (flowmpm_download_field_static)
 
     bool profiling = false;      // the launches being enqueued right now are timed
     int profile_stride = 0;      // 0 off, k: every k-th step of flowmpm_step
@@ -628,6 +660,7 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
     int rc = FLOWMPM_OK;
     auto body = [&]() -> int {
         HIP_TRY(s, hipSetDevice(c.device));
+        HIP_TRY(s, scratch_setup(c.device, &s->static_field));
         if (c.external_stream) {
             s->stream = reinterpret_cast<hipStream_t>(c.stream);
         } else {
@@ -876,30 +909,64 @@ int flowmpm_set_num_particles(flowmpm_sim *s, int64_t count)
     return FLOWMPM_OK;
 }
 
+static int field_columns(flowmpm_sim *s, int32_t field, int *slot, int *width)
+{
+    switch (field) {
+    case FLOWMPM_FIELD_POSITION: *slot = mpm::kPosX; *width = 3; break;
+    case FLOWMPM_FIELD_VELOCITY: *slot = mpm::kVelX; *width = 3; break;
+    case FLOWMPM_FIELD_DENSITY: *slot = mpm::kDensity; *width = 1; break;
+    case FLOWMPM_FIELD_COLOR: *slot = mpm::kColR; *width = 3; break;
+    case FLOWMPM_FIELD_DIRECTION: *slot = mpm::kDirX; *width = 3; break;
+    case FLOWMPM_FIELD_MASS: *slot = mpm::kMass; *width = 1; break;
+    default: return fail(s, FLOWMPM_ERR_INVALID, "unknown field");
+    }
+    return FLOWMPM_OK;
+}
+
 int flowmpm_download_field(flowmpm_sim *s, int32_t field, float *out, int64_t capacity)
 {
     CHECK_SIM(s);
     if (s->slab) return fail(s, FLOWMPM_ERR_INVALID, "download_field is for single-GPU handles");
     int slot, width;
-    switch (field) {
-    case FLOWMPM_FIELD_POSITION: slot = mpm::kPosX; width = 3; break;
-    case FLOWMPM_FIELD_VELOCITY: slot = mpm::kVelX; width = 3; break;
-    case FLOWMPM_FIELD_DENSITY: slot = mpm::kDensity; width = 1; break;
-    case FLOWMPM_FIELD_COLOR: slot = mpm::kColR; width = 3; break;
-    case FLOWMPM_FIELD_DIRECTION: slot = mpm::kDirX; width = 3; break;
-    case FLOWMPM_FIELD_MASS: slot = mpm::kMass; width = 1; break;
-    default: return fail(s, FLOWMPM_ERR_INVALID, "unknown field");
-    }
+    int rc = field_columns(s, field, &slot, &width);
+    if (rc) return rc;
     const long long n = s->resident;
     if (!out || capacity < n) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
     if (n == 0) return FLOWMPM_OK;
     void *stage = nullptr;
-    int rc = stage_device(s, (size_t)n * width * sizeof(float), &stage);
-    if (rc) return rc;
+    if ((rc = stage_device(s, (size_t)n * width * sizeof(float), &stage))) return rc;
     hipLaunchKernelGGL(mpm::gather_field_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->store, n,
                        slot, width, static_cast<float *>(stage));
     if ((rc = launch_check(s, "gather_field"))) return rc;
     return copy_out_and_wait(s, out, stage, (size_t)n * width * sizeof(float), "download_field");
+}
+
+// flowmpm_download_field without any allocation: the id-ordered values are staged in this device's
+// `scratch` array (s->static_field, never the array's name) instead of the handle's staging buffer.
+int flowmpm_download_field_static(flowmpm_sim *s, int32_t field, float *out, int64_t capacity)
+{
+    CHECK_SIM(s);
+    if (s->slab) return fail(s, FLOWMPM_ERR_INVALID, "download_field_static is for single-GPU handles");
+    int slot, width;
+    int rc = field_columns(s, field, &slot, &width);
+    if (rc) return rc;
+    const long long n = s->resident;
+    if (n > kStaticFieldParticles) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "download_field_static holds at most %lld particles, the handle has %lld live: "
+                                  "use flowmpm_download_field", kStaticFieldParticles, n);
+        return fail(s, FLOWMPM_ERR_CAPACITY, buf);
+    }
+    if (!out || capacity < n) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
+    if (n == 0) return FLOWMPM_OK;
+    float *stage = s->static_field;
+    if (!stage) return fail(s, FLOWMPM_ERR_HIP, "the static staging array was not set up on this device");
+    hipLaunchKernelGGL(mpm::gather_field_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->store, n,
+                       slot, width, stage);
+    if ((rc = launch_check(s, "gather_field"))) return rc;
+    HIP_TRY(s, hipMemcpyAsync(out, stage, (size_t)n * width * sizeof(float), hipMemcpyDefault, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    return FLOWMPM_OK;
 }
 
 int flowmpm_get_local_grid(flowmpm_sim *s, int32_t *x_first, int32_t *x_planes)

@@ -133,6 +133,14 @@ class Handle:
         self._chk(self.L.flowmpm_download_field(self._h, int(field), _fp(out), out.shape[0]))
         return out[:live]
 
+    def download_field_static(self, field):
+        """download_field through the library's static device array: no allocation, at most
+        262,144 particles."""
+        live, _ = self.num_particles()
+        out = np.zeros((max(live, 1), _lib.FIELD_WIDTH[field]), dtype=np.float32)
+        self._chk(self.L.flowmpm_download_field_static(self._h, int(field), _fp(out), out.shape[0]))
+        return out[:live]
+
     def local_grid(self):
         x0, nx = ctypes.c_int32(), ctypes.c_int32()
         self._chk(self.L.flowmpm_get_local_grid(self._h, ctypes.byref(x0), ctypes.byref(nx)))

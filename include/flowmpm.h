@@ -285,6 +285,17 @@ int flowmpm_reset_timings(flowmpm_sim *sim);
  * flowmpm_create; it stops growing once the buffers have reached the size of the largest transfer. */
 int flowmpm_get_allocation_count(flowmpm_sim *sim, int64_t *count);
 
+/* flowmpm_download_field for callers that cannot allocate (code under HIP graph capture, tight
+ * per-frame loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * arguments and results as flowmpm_download_field, but the id-ordered values are staged in a static
+ * device array of the library (3 MiB per GPU the library has created a handle on, held until the
+ * process ends) instead of the handle's staging buffer, and nothing is allocated or freed: `out` may
+ * be device memory, pinned host memory, or pageable host memory (which the HIP runtime stages through
+ * its own pool).  At most 262,144 live particles (conf.maxParticles, src/conf.js:8); more is
+ * FLOWMPM_ERR_CAPACITY.  All handles on one GPU share that GPU's array: calls that overlap in time on
+ * one GPU race; calls from one host thread never overlap, because each waits for its copy. */
+int flowmpm_download_field_static(flowmpm_sim *sim, int32_t field, float *out, int64_t capacity);
+
 /* ---- Slab decomposition (no reference counterpart: the reference is single-GPU).
  * The caller owns the transport (RCCL through torch.distributed) and its device buffers;
  * these are the device-side pieces. ---- */
