@@ -237,7 +237,9 @@ def run_single(args):
     seed = 0xF10E5EED + 3
     uniforms = scene_uniforms(n, cells, args.scene, args.noise)
     algo = {"tiled": _lib.ALGO_TILED, "tiled_unfused": _lib.ALGO_TILED_UNFUSED, "scatter": _lib.ALGO_SCATTER}[args.algorithm]
-    h = flow_amd.Handle(grid, n, device=0, algorithm=algo, rebin_interval=args.rebin_interval)
+    # FLOWMPM_BENCH_PAD: extra particle slots, for experiments with the stride between the store's columns
+    h = flow_amd.Handle(grid, n + int(os.environ.get("FLOWMPM_BENCH_PAD", "0")), device=0, algorithm=algo,
+                        rebin_interval=args.rebin_interval)
     rec = make_particles(args.scene, n, grid, seed)
     max_per_cell = None
     if args.scene == "dam_break":        # how crowded the column starts out
@@ -307,6 +309,8 @@ def run_single(args):
                                                 - (before["rebin"].get("stragglers") or 0)) / steady_steps, 1)}
         steady_kernels = {name: {"ms": after[name]["ms"] - before[name]["ms"],
                                  "launches": after[name]["launches"] - before[name]["launches"]} for name in BYTES}
+        steady["kernel_avg_ms"] = {name: round(t["ms"] / t["launches"], 4)
+                                   for name, t in steady_kernels.items() if t["launches"]}
     h.close()
     roof, per_kernel = roofline_of(timings, n, cells)
     rebin_in_window = bool(timings["rebin"].get("performed"))

@@ -83,6 +83,10 @@ struct flowmpm_sim {
     long long uploaded = 0;      // records given to upload (single GPU)
     mpm::StoreSel store{};       // tiled: two stores, re-binning gathers from one into the other
     int drift_divisor = 256;      // re-bin when (particles outside their arena) * divisor > particles
+    // flowmpm_step of a single-domain handle on the two-pass tiled algorithm lets a re-bin ride on the
+    // step's own stores (mpm::RebinCtl::riding) instead of moving every record once more
+    // (FLOWMPM_RIDE_REBINS=0 switches that off, for A/B runs).
+    bool ride_rebins = false;
     int4 *cell = nullptr;        // momentum words (word 3 unused on the device)
     int *mass_i = nullptr;       // mass words, one per cell
     // The float grid is non-zero only where this buffer is positive: the mass words of the step
@@ -273,7 +277,7 @@ int stage_clear_grid(flowmpm_sim *s, bool float_grid = true)
     return launch_check(s, "clear_grid");
 }
 
-int stage_rebin_if_needed(flowmpm_sim *s);
+int stage_rebin_if_needed(flowmpm_sim *s, bool ride = false);
 inline bool is_tiled(const flowmpm_sim *s);
 
 // Before a p2g stage that sets no tile bits itself: if the stage that sets them has not run on
@@ -471,17 +475,19 @@ int stage_g2p(flowmpm_sim *s, int part = 0)
 
 // Tiled algorithm: particles must be grouped by grid tile before the first
 // particle kernel of a step; regroup when the grouping is missing or stale.
-int stage_rebin_if_needed(flowmpm_sim *s)
+// ride: the caller is flowmpm_step on the two-pass tiled algorithm, whose momentum pass and g2p stage
+// follow in this step and complete a re-bin found due (mpm::rebin_if_due).
+int stage_rebin_if_needed(flowmpm_sim *s, bool ride)
 {
     mpm::TiledState &T = s->tiled;
     if (T.valid && T.checked) return FLOWMPM_OK;
     if (s->live == 0) return FLOWMPM_OK;
-    TimedLaunch t;      // from the start of the first binning kernel to the end of the second
+    TimedLaunch t;      // from the start of the first binning kernel to the end of the last
     int rc = timing_events(s, FLOWMPM_TIMING_REBIN, &t);
     if (rc) return rc;
     std::string msg;
     if (mpm::rebin_if_due(T, s->store, s->live, s->params, s->cfg.rebin_interval, s->drift_divisor, s->stream,
-                          t.start, t.stop, &msg))
+                          t.start, t.stop, &msg, ride && s->ride_rebins))
         return fail(s, FLOWMPM_ERR_HIP, "rebin: " + msg);
     return FLOWMPM_OK;
 }
@@ -693,6 +699,12 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
             // it pays to carry more of them for longer (measured on slabs of the 8-slab decomposition
             // of 2^27 particles: 256 -> 2.57, 96 -> 2.44, 48 -> 2.34, 24 -> 2.35, 12 -> 2.36 ms per step).
             if (s->slab) s->drift_divisor = 48;
+            s->ride_rebins = !s->slab && c.algorithm == FLOWMPM_ALGO_TILED;
+            if (const char *env = getenv("FLOWMPM_RIDE_REBINS")) s->ride_rebins = s->ride_rebins && atoi(env) != 0;
+            // A riding re-bin costs half of a standalone one, and the step it rides on still runs on the old
+            // binning: it pays to start it earlier (steady state of the benchmark scene, noise uniform 0 / 1:
+            // divisor 256 -> 10.17 / 7.78e9 per second, 512 -> 10.24 / 7.98, 1024 -> 10.22 / 7.98, 2048 -> 10.28 / 8.04).
+            if (s->ride_rebins) s->drift_divisor = 1024;
             if (const char *env = getenv("FLOWMPM_DRIFT_DIVISOR")) s->drift_divisor = atoi(env);
             HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->dirty), (size_t)s->tiled.n_tiles * sizeof(int)));
             HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
@@ -837,6 +849,8 @@ int flowmpm_step(flowmpm_sim *s, int32_t n_steps, double dtime)
         s->profiling = s->profile_stride > 0 && (s->profile_step++ % s->profile_stride) == 0;
         if ((rc = stage_clear_grid(s, false))) break;
         if (s->cfg.algorithm == FLOWMPM_ALGO_TILED) {
+            // the binning decision of the step; a re-bin rides on the passes below
+            if (s->live > 0 && (rc = stage_rebin_if_needed(s, true))) break;
             if ((rc = stage_p2g_pass(s, false))) break;
             if ((rc = stage_p2g_pass(s, true))) break;
         } else {
@@ -1048,6 +1062,21 @@ int flowmpm_get_allocation_count(flowmpm_sim *s, int64_t *count)
     *count = s->stage_allocations + s->migration.allocations;
     return FLOWMPM_OK;
 }
+
+#if FLOWMPM_STAMPS
+// Diagnostic build only: copies the clock stamps of `kernel` (0 momentum pass, 1 g2p) to the host,
+// `slots` pairs of {shader cycles, 100 MHz ticks}.
+int flowmpm_debug_clock_stamps(flowmpm_sim *s, int32_t kernel, uint64_t *out, int64_t slots)
+{
+    CHECK_SIM(s);
+    if (kernel < 0 || kernel > 1 || !out || slots < 1 || slots > mpm::kStampSlots)
+        return fail(s, FLOWMPM_ERR_INVALID, "bad stamp request");
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    HIP_TRY(s, hipMemcpyFromSymbol(out, HIP_SYMBOL(mpm::g_clock_stamps), (size_t)slots * 2 * sizeof(uint64_t),
+                                   (size_t)kernel * mpm::kStampSlots * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return FLOWMPM_OK;
+}
+#endif
 
 // ---- slab decomposition --------------------------------------------------------
 

@@ -63,6 +63,37 @@ constexpr int kTiledThreads = 256;
 #define FLOWMPM_PREFETCH_P2G 0
 #endif
 
+// Diagnostic build only (-DFLOWMPM_STAMPS=1, tools/clock_stamps.py): every workgroup of the momentum
+// pass and of g2p stamps the shader clock (s_memtime, one tick per shader cycle) and the constant
+// 100 MHz clock (s_memrealtime) around its particle loop; their quotient is the clock the chip held
+// under this load.  The stamps go to an array nothing else reads; no stamp executes in a normal build.
+#ifndef FLOWMPM_STAMPS
+#define FLOWMPM_STAMPS 0
+#endif
+#if FLOWMPM_STAMPS
+constexpr int kStampSlots = 1 << 15;
+__device__ unsigned long long g_clock_stamps[2][kStampSlots][2];      // [kernel][workgroup][shader, real]
+struct ClockStamp {
+    unsigned long long t0, r0;
+    __device__ __forceinline__ void begin()
+    {
+        if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    }
+    __device__ __forceinline__ void end(int kernel)
+    {
+        if (threadIdx.x == 0 && blockIdx.x < (unsigned)kStampSlots) {
+            g_clock_stamps[kernel][blockIdx.x][0] = __builtin_amdgcn_s_memtime() - t0;
+            g_clock_stamps[kernel][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - r0;
+        }
+    }
+};
+#else
+struct ClockStamp {
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ void end(int) {}
+};
+#endif
+
 // Particles whose stencil no longer fits their bin's arena (they drifted since the last
 // re-bin) are not handled by the tiled kernels: their slot index is appended here and a
 // small follow-up kernel sends their contributions straight to the global grid.  Keeping
@@ -89,7 +120,13 @@ struct RebinCtl {
     unsigned long long stragglers;   // particles the g2p stages since then handed to the follow-up kernel
     unsigned long long t_start;      // ~0 when no re-bin is in flight
     int epoch;       // re-bins performed since the store was created (never cleared): slot indices
-    int unused;      // taken under one epoch are stale under the next
+                     // taken under one epoch are stale under the next
+    // A re-bin that "rides" on a step: the step's first launch decides it, counts the tiles and builds
+    // the next item set; the momentum pass and g2p of the same step then store what they store anyway
+    // into the particle's slot of the OTHER store, and the last workgroup of the step commits.
+    int riding;      // latched by the step's binning launch: this step's stores go to the other store
+    int drift_next;  // particles g2p leaves outside the arena of their NEW tile during a riding re-bin
+    int item_set;    // which of the two item sets (work items, tile_start) is current
 };
 
 struct TiledState {
@@ -101,9 +138,11 @@ struct TiledState {
     int *key = nullptr;          // per slot: tile id
     int *rank = nullptr;         // per slot: position inside its tile's run
     int *tile_count = nullptr;   // [n_tiles]
-    int *tile_start = nullptr;   // [n_tiles + 1]
-    int4 *items = nullptr;       // work items {tile, begin, end, 0}
-    int *n_items = nullptr;      // device scalar
+    // Two sets of each (RebinCtl::item_set says which is current): a re-bin builds the other set
+    // while the kernels of the step it rides on still read the current one.
+    int *tile_start = nullptr;   // 2 x [n_tiles + 1]
+    int4 *items = nullptr;       // 2 x item_cap work items {tile, begin, end, 0}
+    int *n_items = nullptr;      // 2 device scalars
     int *straggler_counts = nullptr;   // two device scalars used by alternate stages
     int *straggler_list = nullptr;
     int stage_parity = 0;        // which of the two the next stage counts into
@@ -120,8 +159,12 @@ struct TileDims { int tiles_x, tiles_y, tiles_z; };
 // What a tiled particle kernel needs to find its particles.
 struct TiledWork {
     StoreSel store;
-    const int4 *items;
+    const int4 *items;           // both sets (TiledState)
     const int *n_items;
+    long long item_cap;
+    // of the re-bin in flight (read only while RebinCtl::riding is set)
+    const int *key, *rank, *tile_start;
+    int n_tiles;
     RebinCtl *ctl;
     int n;                       // live particles: items are clipped to [0, n)
     TileDims td;
@@ -240,9 +283,18 @@ __global__ void __launch_bounds__(256)
 bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict__ key, int *__restrict__ rank,
                       int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
                       int4 *__restrict__ items, int *__restrict__ n_items_out, long long item_cap,
-                      RebinCtl *ctl, int interval, int force, int divisor)
+                      RebinCtl *ctl, int interval, int force, int divisor, int ride)
 {
-    if (!rebin_due(ctl, n, interval, force, divisor)) return;
+    // tile_start, items, n_items_out: both sets; this launch fills the one that is not current.
+    // ride: the re-bin, if due, rides on this step (RebinCtl::riding) instead of being completed by
+    // bin_scatter_kernel.  The decision is a pure function of words nothing changes before g2p.
+    const bool due = rebin_due(ctl, n, interval, force, divisor);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->riding = (ride && due) ? 1 : 0;
+    if (!due) return;
+    const int next_set = ctl->item_set ^ 1;
+    tile_start += (long long)next_set * (n_tiles + 1);
+    items += (long long)next_set * item_cap;
+    n_items_out += next_set;
     if (threadIdx.x == 0) atomicMin(&ctl->t_start, (unsigned long long)wall_clock64());
     const Store st = ss.pick();
     const int lane = threadIdx.x & 63;
@@ -275,7 +327,13 @@ bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict
         base = __shfl(base, leader);
         if (valid) { key[j] = k; rank[j] = base + pos; }
     }
-    if (last_workgroup(&ctl->ticket)) scan_tiles(tile_count, n_tiles, tile_start, items, n_items_out, item_cap);
+    if (last_workgroup(&ctl->ticket)) {
+        scan_tiles(tile_count, n_tiles, tile_start, items, n_items_out, item_cap);
+        if (ride && threadIdx.x == 0) {      // a riding re-bin's own device time ends here
+            ctl->busy_ticks += (unsigned long long)wall_clock64() - ctl->t_start;
+            ctl->t_start = ~0ULL;
+        }
+    }
 }
 
 // Second launch: every record moves to its slot of the other store (reads coalesced; writes
@@ -283,9 +341,11 @@ bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict
 // store becomes current.
 __global__ void __launch_bounds__(256)
 bin_scatter_kernel(StoreSel ss, int n, const int *__restrict__ key, const int *__restrict__ rank,
-                   const int *__restrict__ tile_start, RebinCtl *ctl, int interval, int force, int divisor)
+                   const int *__restrict__ tile_start, int n_tiles, RebinCtl *ctl, int interval, int force,
+                   int divisor)
 {
     if (!rebin_due(ctl, n, interval, force, divisor)) return;
+    tile_start += (long long)(ctl->item_set ^ 1) * (n_tiles + 1);      // the set the first launch filled
     const Store src = ss.pick(), dst = ss.other();
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
@@ -295,6 +355,7 @@ bin_scatter_kernel(StoreSel ss, int n, const int *__restrict__ key, const int *_
     }
     if (last_workgroup(&ctl->ticket) && threadIdx.x == 0) {
         ctl->cur ^= 1;
+        ctl->item_set ^= 1;
         ctl->age = 0;
         ctl->cum_drift = 0;
         ctl->binned = n;
@@ -462,9 +523,10 @@ __device__ __forceinline__ int item_for_block(int n_items)
 // The work item of this workgroup, clipped to the live particles; false when there is none.
 __device__ __forceinline__ bool take_item(const TiledWork &w, int4 *item)
 {
-    const int id = item_for_block(*w.n_items);
+    const int set = w.ctl->item_set;
+    const int id = item_for_block(w.n_items[set]);
     if (id < 0) return false;
-    *item = w.items[id];
+    *item = w.items[(long long)set * w.item_cap + id];
     item->z = min(item->z, w.n);
     if (w.part != 0) {
         const int tx = item->x / (w.td.tiles_y * w.td.tiles_z);
@@ -472,6 +534,23 @@ __device__ __forceinline__ bool take_item(const TiledWork &w, int4 *item)
         if (boundary != (w.part == 2)) return false;
     }
     return item->y < item->z;
+}
+
+// Where a kernel stores a particle's record while a re-bin rides on the step: slot
+// tile_start[key] + rank of the other store (key, rank and the next set's tile_start were written by
+// this step's binning launch).  Off: the particle's own slot of the current store.
+struct Ride {
+    bool on;
+    Store dst;
+    const int *key, *rank, *start;
+    __device__ __forceinline__ int slot(int j) const { return on ? start[key[j]] + rank[j] : j; }
+};
+
+__device__ __forceinline__ Ride ride_of(const TiledWork &w, const Store &cur)
+{
+    const bool on = w.ctl->riding != 0;
+    return Ride{on, on ? w.store.other() : cur, w.key, w.rank,
+                w.tile_start + (long long)(w.ctl->item_set ^ 1) * (w.n_tiles + 1)};
 }
 
 // ---- p2g1 (SIM:295-333) ------------------------------------------------------------
@@ -735,8 +814,8 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 
 template <bool INSIDE>
 __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx, float vy, float vz,
-                                                      const float C[9], float *dens_slot, int *lds,
-                                                      const float *mass_f, int abase, FixedGrid g,
+                                                      const float C[9], const float *dens_slot, float *dens_out,
+                                                      int *lds, const float *mass_f, int abase, FixedGrid g,
                                                       const Params &P)
 {
     float density = 0.0f;
@@ -758,7 +837,7 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
                 density = density + m * weight;
             }
         }
-    *dens_slot = *dens_slot * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
+    *dens_out = *dens_slot * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
     Eq16 e = p2g2_stress(density, C, P);
 #pragma unroll
     for (int gx = 0; gx < 3; gx++)
@@ -818,6 +897,10 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     }
     __syncthreads();
     const Column<float> dens = st.slot(kDensity);
+    const Ride ride = ride_of(w, st);
+    const Column<float> dens_out = ride.dst.slot(kDensity);
+    ClockStamp stamp;
+    stamp.begin();
     // Software pipeline: the next particle's 15 loads are issued before this particle's LDS
     // atomics and density store, so an iteration never starts by waiting on memory.
     float in[15];
@@ -838,7 +921,8 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
         int abase;
         if (stencil_in_arena(s, A, &abase))
-            p2g_momentum_particle<true>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + j, lds, mass_f, abase, g, P);
+            p2g_momentum_particle<true>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + j,
+                                        dens_out + ride.slot(j), lds, mass_f, abase, g, P);
         else
             add_straggler(sg, sb, j);
 #if FLOWMPM_PREFETCH_P2G
@@ -852,6 +936,7 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 #endif
         j = jn;
     }
+    stamp.end(0);
     straggler_buf_flush(sg, sb);
     __syncthreads();
     flush_arena<3>(lds, A, P, g);
@@ -947,10 +1032,15 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
     int j = item.y + threadIdx.x;
     auto load = [&](G2PIn &r, int q) {
         r.px = st.slot(kPosX)[q]; r.py = st.slot(kPosY)[q]; r.pz = st.slot(kPosZ)[q];
-        r.mass = st.slot(kMass)[q];
+        // the mass is read by the mouse force alone (SIM:1354-1360)
+        r.mass = P.cursor_interaction == 1u ? st.slot(kMass)[q] : 0.0f;
         r.dirx = st.slot(kDirX)[q]; r.diry = st.slot(kDirY)[q]; r.dirz = st.slot(kDirZ)[q];
     };
     int drifted = 0;    // particles this thread leaves outside the arena: stragglers of the next step
+    const Ride ride = ride_of(w, st);
+    const Store out = ride.dst;
+    ClockStamp stamp;
+    stamp.begin();
     if (j < item.z) load(in, j);
     while (j < item.z) {
         const int jn = j + kTiledThreads;
@@ -982,13 +1072,28 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
             __builtin_amdgcn_sched_barrier(0);
 #endif
             G2POut o = MODES ? g2p_finish_modes(in, v, B, index, hide, P, M) : g2p_finish(in, v, B, P);
+            // While a re-bin rides on this step the record goes to its slot of the other store, and the
+            // columns no kernel of the step writes travel with it (the density went there with the
+            // momentum pass); the drift is then counted against the arena of the particle's new tile.
+            int d = j;
+            Arena An = A;
+            if (ride.on) {
+                const int tile = ride.key[j];
+                d = ride.start[tile] + ride.rank[j];
+                An = arena_of_tile(tile, w.td, P);
+                out.slot(kMass)[d] = st.slot(kMass)[j];
+                out.slot(kColR)[d] = st.slot(kColR)[j];
+                out.slot(kColG)[d] = st.slot(kColG)[j];
+                out.slot(kColB)[d] = st.slot(kColB)[j];
+                out.ids()[d] = st.ids()[j];
+            }
 #pragma unroll
-            for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
-            st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;
-            st.slot(kVelX)[j] = o.vx; st.slot(kVelY)[j] = o.vy; st.slot(kVelZ)[j] = o.vz;
-            st.slot(kDirX)[j] = o.dirx; st.slot(kDirY)[j] = o.diry; st.slot(kDirZ)[j] = o.dirz;
-            const int bx = f32_to_i32(o.px) - 1 - A.ox, by = f32_to_i32(o.py) - 1 - A.oy,
-                      bz = f32_to_i32(o.pz) - 1 - A.oz;
+            for (int k = 0; k < 9; k++) out.slot(kC00 + k)[d] = o.C[k];
+            out.slot(kPosX)[d] = o.px; out.slot(kPosY)[d] = o.py; out.slot(kPosZ)[d] = o.pz;
+            out.slot(kVelX)[d] = o.vx; out.slot(kVelY)[d] = o.vy; out.slot(kVelZ)[d] = o.vz;
+            out.slot(kDirX)[d] = o.dirx; out.slot(kDirY)[d] = o.diry; out.slot(kDirZ)[d] = o.dirz;
+            const int bx = f32_to_i32(o.px) - 1 - An.ox, by = f32_to_i32(o.py) - 1 - An.oy,
+                      bz = f32_to_i32(o.pz) - 1 - An.oz;
             drifted += !((unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
                          (unsigned)bz <= (unsigned)(kAZ - 3));
         } else if (!LISTED) {
@@ -1001,10 +1106,11 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
 #endif
         j = jn;
     }
+    stamp.end(1);
     if (__any(drifted != 0)) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) drifted += __shfl_down(drifted, off);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&w.ctl->cum_drift, drifted);
+        if ((threadIdx.x & 63) == 0) atomicAdd(ride.on ? &w.ctl->drift_next : &w.ctl->cum_drift, drifted);
     }
 }
 
@@ -1094,8 +1200,9 @@ straggler_p2g_team_kernel(TiledWork w, FixedGrid g, Params P)
         float density = 0.0f;
         for (int k = 0; k < 27; k++) density = density + __shfl(term, team_lane0 + k);
         if (live && c == 0) {
-            float *dens_slot = st.slot(kDensity) + j;
-            *dens_slot = *dens_slot * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
+            const Ride ride = ride_of(w, st);
+            ride.dst.slot(kDensity)[ride.slot(j)] =
+                st.slot(kDensity)[j] * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
         }
         const Eq16 e = p2g2_stress(density, C, P);
         const float dx = pick3(s.dx, gx), dy = pick3(s.dy, gy), dz = pick3(s.dz, gz);
@@ -1127,18 +1234,24 @@ straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
     const Store st = w.store.pick();
     int count, tail_begin;
     const int total = straggler_total(w, &count, &tail_begin);
+    const Ride ride = ride_of(w, st);
+    const Store out = ride.dst;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *w.sg.next_count = 0;
-        // bookkeeping of the step that ends here: every particle on this path counts as outside
-        if (total) atomicAdd(&w.ctl->cum_drift, total);
-        w.ctl->age += 1;
         w.ctl->stragglers += (unsigned long long)total;
+        // bookkeeping of the step that ends here: every particle on this path counts as outside
+        // (not while a re-bin rides on the step: these particles are being binned anew)
+        if (!ride.on) {
+            if (total) atomicAdd(&w.ctl->cum_drift, total);
+            w.ctl->age += 1;
+        }
     }
+    int drifted = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int j = i < count ? w.sg.list[i] : tail_begin + (i - count);
         G2PIn in;
         in.px = st.slot(kPosX)[j]; in.py = st.slot(kPosY)[j]; in.pz = st.slot(kPosZ)[j];
-        in.mass = st.slot(kMass)[j];
+        in.mass = P.cursor_interaction == 1u ? st.slot(kMass)[j] : 0.0f;
         in.dirx = st.slot(kDirX)[j]; in.diry = st.slot(kDirY)[j]; in.dirz = st.slot(kDirZ)[j];
         Vec3 v;
         int index = 0;
@@ -1157,11 +1270,42 @@ straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
         for (int k = 0; k < 9; k++) B[k] = 0.0f;
         if (!MODES || (M->grid_mode == 0u && !hide)) g2p_gather<false>(s, nullptr, 0, cellf, P, v, B);
         G2POut o = MODES ? g2p_finish_modes(in, v, B, index, hide, P, M) : g2p_finish(in, v, B, P);
+        int d = j;
+        if (ride.on) {            // as in g2p_tiled_kernel
+            const int tile = ride.key[j];
+            d = ride.start[tile] + ride.rank[j];
+            const Arena An = arena_of_tile(tile, w.td, P);
+            out.slot(kMass)[d] = st.slot(kMass)[j];
+            out.slot(kColR)[d] = st.slot(kColR)[j];
+            out.slot(kColG)[d] = st.slot(kColG)[j];
+            out.slot(kColB)[d] = st.slot(kColB)[j];
+            out.ids()[d] = st.ids()[j];
+            const int bx = f32_to_i32(o.px) - 1 - An.ox, by = f32_to_i32(o.py) - 1 - An.oy,
+                      bz = f32_to_i32(o.pz) - 1 - An.oz;
+            drifted += !((unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
+                         (unsigned)bz <= (unsigned)(kAZ - 3));
+        }
 #pragma unroll
-        for (int k = 0; k < 9; k++) st.slot(kC00 + k)[j] = o.C[k];
-        st.slot(kPosX)[j] = o.px; st.slot(kPosY)[j] = o.py; st.slot(kPosZ)[j] = o.pz;
-        st.slot(kVelX)[j] = o.vx; st.slot(kVelY)[j] = o.vy; st.slot(kVelZ)[j] = o.vz;
-        st.slot(kDirX)[j] = o.dirx; st.slot(kDirY)[j] = o.diry; st.slot(kDirZ)[j] = o.dirz;
+        for (int k = 0; k < 9; k++) out.slot(kC00 + k)[d] = o.C[k];
+        out.slot(kPosX)[d] = o.px; out.slot(kPosY)[d] = o.py; out.slot(kPosZ)[d] = o.pz;
+        out.slot(kVelX)[d] = o.vx; out.slot(kVelY)[d] = o.vy; out.slot(kVelZ)[d] = o.vz;
+        out.slot(kDirX)[d] = o.dirx; out.slot(kDirY)[d] = o.diry; out.slot(kDirZ)[d] = o.dirz;
+    }
+    if (!ride.on) return;                                   // uniform over the launch
+    if (drifted) atomicAdd(&w.ctl->drift_next, drifted);
+    // The riding re-bin is complete when every workgroup of this launch -- the last one of the step --
+    // has stored its records: the last one to finish makes the other store and item set current.
+    if (last_workgroup(&w.ctl->ticket) && threadIdx.x == 0) {
+        RebinCtl *ctl = w.ctl;
+        ctl->cur ^= 1;
+        ctl->item_set ^= 1;
+        ctl->age = 1;               // the new binning is of the positions before this step's g2p
+        ctl->cum_drift = __hip_atomic_load(&ctl->drift_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl->drift_next = 0;
+        ctl->binned = w.n;
+        ctl->rebins += 1;
+        ctl->epoch += 1;
+        ctl->riding = 0;
     }
 }
 
@@ -1252,10 +1396,10 @@ inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStr
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.rank), (size_t)capacity * sizeof(int)), "hipMalloc rank")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.tile_count), (size_t)T.n_tiles * sizeof(int)), "hipMalloc tile_count")) return 1;
     if (chk(e = hipMemsetAsync(T.tile_count, 0, (size_t)T.n_tiles * sizeof(int), stream), "memset tile_count")) return 1;
-    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.tile_start), (size_t)(T.n_tiles + 1) * sizeof(int)), "hipMalloc tile_start")) return 1;
-    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.items), (size_t)T.item_cap * sizeof(int4)), "hipMalloc items")) return 1;
-    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.n_items), sizeof(int)), "hipMalloc n_items")) return 1;
-    if (chk(e = hipMemsetAsync(T.n_items, 0, sizeof(int), stream), "memset n_items")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.tile_start), 2 * (size_t)(T.n_tiles + 1) * sizeof(int)), "hipMalloc tile_start")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.items), 2 * (size_t)T.item_cap * sizeof(int4)), "hipMalloc items")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.n_items), 2 * sizeof(int)), "hipMalloc n_items")) return 1;
+    if (chk(e = hipMemsetAsync(T.n_items, 0, 2 * sizeof(int), stream), "memset n_items")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.straggler_counts), 256), "hipMalloc straggler counts")) return 1;
     if (chk(e = hipMemsetAsync(T.straggler_counts, 0, 256, stream), "memset straggler counts")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.straggler_list), (size_t)capacity * sizeof(int)), "hipMalloc straggler list")) return 1;
@@ -1292,17 +1436,25 @@ constexpr unsigned kBinBlocks = FLOWMPM_BIN_BLOCKS;
 // Enqueues the start-of-step pair of launches (see "binning" above).  When a re-bin is due the
 // first n particles of the current store are grouped by tile into the other store, the work
 // items are rebuilt and the other store becomes current.
+//
+// ride: only the first launch is enqueued; a re-bin it finds due is completed by the momentum pass and
+// the g2p stage of the same step, which must follow (flowmpm_step's order): they store what they store
+// anyway into the other store, at the particle's new slot, so the records are not moved a second time.
+// A forced re-bin (new particles: no binning to run the step's first passes on) never rides.
 inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P, int interval, int divisor,
-                        hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, std::string *msg)
+                        hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, std::string *msg,
+                        bool ride = false)
 {
     const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, kBinBlocks);
     const int force = T.valid ? 0 : 1;
+    if (force) ride = false;
     T.listed = -1;
-    hipExtLaunchKernelGGL(bin_count_scan_kernel, dim3(blocks), dim3(256), 0, stream, ev_start, nullptr, 0, ss, (int)n,
-                          P, tile_dims(T), T.key, T.rank, T.tile_count, T.n_tiles, T.tile_start, T.items, T.n_items,
-                          T.item_cap, T.ctl, interval, force, divisor);
-    hipExtLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, stream, nullptr, ev_stop, 0, ss, (int)n,
-                          T.key, T.rank, T.tile_start, T.ctl, interval, force, divisor);
+    hipExtLaunchKernelGGL(bin_count_scan_kernel, dim3(blocks), dim3(256), 0, stream, ev_start, ride ? ev_stop : nullptr,
+                          0, ss, (int)n, P, tile_dims(T), T.key, T.rank, T.tile_count, T.n_tiles, T.tile_start, T.items,
+                          T.n_items, T.item_cap, T.ctl, interval, force, divisor, ride ? 1 : 0);
+    if (!ride)
+        hipExtLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, stream, nullptr, ev_stop, 0, ss, (int)n,
+                              T.key, T.rank, T.tile_start, T.n_tiles, T.ctl, interval, force, divisor);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { *msg = std::string("rebin launch: ") + hipGetErrorString(e); return 1; }
     T.valid = true;
@@ -1323,8 +1475,8 @@ inline TiledWork tiled_work(TiledState &T, StoreSel ss, long long n, StagePart s
     const Stragglers sg{T.straggler_counts + T.stage_parity, T.straggler_counts + (T.stage_parity ^ 1),
                         T.straggler_list};
     if (sp.part != 1) T.stage_parity ^= 1;
-    return TiledWork{ss, T.items, T.n_items, T.ctl, (int)n, tile_dims(T), sg, -2147483647 - 1, 2147483647,
-                     sp.part, sp.bnd_lo, sp.bnd_hi};
+    return TiledWork{ss, T.items, T.n_items, T.item_cap, T.key, T.rank, T.tile_start, T.n_tiles, T.ctl, (int)n,
+                     tile_dims(T), sg, -2147483647 - 1, 2147483647, sp.part, sp.bnd_lo, sp.bnd_hi};
 }
 
 // Upper bound of the work items any binning of n particles can produce.
