@@ -34,7 +34,11 @@ constexpr int kRim = FLOWMPM_RIM;
 constexpr int kAX = kTX + 2 * kRim, kAY = kTY + 2 * kRim, kAZ = kTZ + 2 * kRim;
 constexpr int kArenaCells = kAX * kAY * kAZ;
 constexpr int kArenaPad = kArenaCells + 8;     // component stride in LDS (dwords)
-constexpr int kChunk = 4096;                   // most particles one work item holds
+// Most particles one work item (= one workgroup's run of particles of one tile) holds.  Chosen per
+// binning from the particle count (choose_chunk): a large scene gets the upper bound, where the arena's
+// set-up and flush are amortised best; a small one gets more, smaller items, so that the chip is filled
+// (several workgroups per tile merge through the same integer atomics: bits do not change).
+constexpr int kChunkMax = 4096, kChunkMin = 256;
 constexpr int kTiledThreads = 256;
 // Minimum waves per SIMD the register allocator must leave room for (second argument of
 // __launch_bounds__) in the two register-heavy kernels; measured, not guessed.
@@ -46,6 +50,9 @@ constexpr int kTiledThreads = 256;
 #endif
 #ifndef FLOWMPM_G2P_B128
 #define FLOWMPM_G2P_B128 0   // measured: 16-byte reads cost 8 VGPRs and 2% of g2p
+#endif
+#ifndef FLOWMPM_G2P_READ_ALL
+#define FLOWMPM_G2P_READ_ALL 0
 #endif
 #ifndef FLOWMPM_G2P_PHASE_BARRIERS
 #define FLOWMPM_G2P_PHASE_BARRIERS 0
@@ -145,6 +152,7 @@ struct TiledState {
     int *n_items = nullptr;      // 2 device scalars
     int *straggler_counts = nullptr;   // two device scalars used by alternate stages
     int *straggler_list = nullptr;
+    int chunk = kChunkMax;       // particles per work item of the current binning (choose_chunk)
     int stage_parity = 0;        // which of the two the next stage counts into
     // The counter (0 / 1) under which the last momentum pass or p2g2 listed its stragglers, while the
     // particles are still the ones it saw, in the same slots; -1 otherwise.  g2p then reuses the list.
@@ -229,7 +237,7 @@ __device__ __forceinline__ bool last_workgroup(int *ticket)
 // of the same launch, hence the device-scope loads.
 __device__ __forceinline__ void scan_tiles(int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
                                            int4 *__restrict__ items, int *__restrict__ n_items_out,
-                                           long long item_cap)
+                                           long long item_cap, const int kChunk)
 {
     __shared__ int wave_cnt[4], wave_itm[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -283,7 +291,7 @@ __global__ void __launch_bounds__(256)
 bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict__ key, int *__restrict__ rank,
                       int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
                       int4 *__restrict__ items, int *__restrict__ n_items_out, long long item_cap,
-                      RebinCtl *ctl, int interval, int force, int divisor, int ride)
+                      RebinCtl *ctl, int interval, int force, int divisor, int ride, int chunk)
 {
     // tile_start, items, n_items_out: both sets; this launch fills the one that is not current.
     // ride: the re-bin, if due, rides on this step (RebinCtl::riding) instead of being completed by
@@ -328,7 +336,7 @@ bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict
         if (valid) { key[j] = k; rank[j] = base + pos; }
     }
     if (last_workgroup(&ctl->ticket)) {
-        scan_tiles(tile_count, n_tiles, tile_start, items, n_items_out, item_cap);
+        scan_tiles(tile_count, n_tiles, tile_start, items, n_items_out, item_cap, chunk);
         if (ride && threadIdx.x == 0) {      // a riding re-bin's own device time ends here
             ctl->busy_ticks += (unsigned long long)wall_clock64() - ctl->t_start;
             ctl->t_start = ~0ULL;
@@ -957,6 +965,20 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
     float B8 = B[8];
     Float2v vxy = {v.x, v.y};
     float vz = v.z;
+#if FLOWMPM_G2P_READ_ALL
+    // All 27 arena reads are issued before the first use, so that the round trip to the LDS is paid once
+    // per particle and not once per row of the stencil (left to itself the compiler issues three reads
+    // and waits for them, nine times over).
+    float fx[27], fy[27], fz[27];
+    if (INSIDE) {
+#pragma unroll
+        for (int c = 0; c < 27; c++) {
+            const float4 f = grid[abase + arena_index(c / 9, (c / 3) % 3, c % 3)];
+            fx[c] = f.x; fy[c] = f.y; fz[c] = f.z;
+        }
+        asm volatile("" ::: "memory");
+    }
+#endif
 #pragma unroll
     for (int gx = 0; gx < 3; gx++)
 #pragma unroll
@@ -970,7 +992,11 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                 const float weight = gz == 0 ? w01.x : gz == 1 ? w01.y : w2;
                 float4 f;
                 if (INSIDE) {
+#if FLOWMPM_G2P_READ_ALL
+                    f = make_float4(fx[(gx * 3 + gy) * 3 + gz], fy[(gx * 3 + gy) * 3 + gz], fz[(gx * 3 + gy) * 3 + gz], 0.0f);
+#else
                     f = grid[abase + arena_index(gx, gy, gz)];
+#endif
 #if FLOWMPM_G2P_B128
                     // keep the read 16 bytes wide: ds_read_b128 takes half the LDS cycles of the
                     // ds_read_b96 the compiler picks when only xyz is used
@@ -991,7 +1017,8 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                 vxy = vxy + wvxy;
                 vz = vz + wvz;
             }
-#if FLOWMPM_SLAB_FENCE == 1
+#if FLOWMPM_G2P_READ_ALL
+#elif FLOWMPM_SLAB_FENCE == 1
             // keep the compiler from hoisting all 27 arena reads (108 VGPRs) to the top
             if (INSIDE) asm volatile("" ::: "memory");
 #elif FLOWMPM_SLAB_FENCE == 2
@@ -1386,7 +1413,7 @@ inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStr
     T.tiles_y = (P.gy + kTY - 1) / kTY;
     T.tiles_z = (P.gz + kTZ - 1) / kTZ;
     T.n_tiles = T.tiles_x * T.tiles_y * T.tiles_z;
-    T.item_cap = (long long)T.n_tiles + capacity / kChunk + 1;
+    T.item_cap = (long long)T.n_tiles + capacity / kChunkMin + 1;
     hipError_t e;
     auto chk = [&](hipError_t err, const char *what) {
         if (err != hipSuccess) { *msg = std::string(what) + ": " + hipGetErrorString(err); return true; }
@@ -1433,6 +1460,20 @@ inline void tiled_free(TiledState &T)
 #endif
 constexpr unsigned kBinBlocks = FLOWMPM_BIN_BLOCKS;
 
+// Work-item size for a binning of n particles: about kItemsPerCU items of full size per compute unit,
+// in multiples of the workgroup size, within [kChunkMin, kChunkMax].
+#ifndef FLOWMPM_ITEMS_PER_CU
+#define FLOWMPM_ITEMS_PER_CU 8
+#endif
+inline int choose_chunk(long long n)
+{
+    int per_cu = FLOWMPM_ITEMS_PER_CU;
+    if (const char *env = getenv("FLOWMPM_ITEMS_PER_CU")) per_cu = std::max(1, atoi(env));
+    const long long want = n / (256LL * per_cu);
+    const long long rounded = (want + kTiledThreads - 1) / kTiledThreads * kTiledThreads;
+    return (int)std::min<long long>(kChunkMax, std::max<long long>(kChunkMin, rounded));
+}
+
 // Enqueues the start-of-step pair of launches (see "binning" above).  When a re-bin is due the
 // first n particles of the current store are grouped by tile into the other store, the work
 // items are rebuilt and the other store becomes current.
@@ -1447,11 +1488,14 @@ inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P
 {
     const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, kBinBlocks);
     const int force = T.valid ? 0 : 1;
-    if (force) ride = false;
+    if (force) {
+        ride = false;
+        T.chunk = choose_chunk(n);      // kept until the next forced re-bin: the launch bounds rely on it
+    }
     T.listed = -1;
     hipExtLaunchKernelGGL(bin_count_scan_kernel, dim3(blocks), dim3(256), 0, stream, ev_start, ride ? ev_stop : nullptr,
                           0, ss, (int)n, P, tile_dims(T), T.key, T.rank, T.tile_count, T.n_tiles, T.tile_start, T.items,
-                          T.n_items, T.item_cap, T.ctl, interval, force, divisor, ride ? 1 : 0);
+                          T.n_items, T.item_cap, T.ctl, interval, force, divisor, ride ? 1 : 0, T.chunk);
     if (!ride)
         hipExtLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, stream, nullptr, ev_stop, 0, ss, (int)n,
                               T.key, T.rank, T.tile_start, T.n_tiles, T.ctl, interval, force, divisor);
@@ -1482,7 +1526,7 @@ inline TiledWork tiled_work(TiledState &T, StoreSel ss, long long n, StagePart s
 // Upper bound of the work items any binning of n particles can produce.
 inline unsigned item_bound(const TiledState &T, long long n)
 {
-    long long b = std::min<long long>(T.item_cap, std::min<long long>((long long)T.n_tiles, n) + n / kChunk + 1);
+    long long b = std::min<long long>(T.item_cap, std::min<long long>((long long)T.n_tiles, n) + n / T.chunk + 1);
     return (unsigned)std::max<long long>(b, 1);
 }
 

@@ -1,6 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r01e}
+TAG=${1:-r02c}
 mkdir -p gpurun_out/$TAG
 export TMPDIR=/tmp
 timeout -k 10 300 python bench.py > gpurun_out/$TAG/bench_16M_256cube.json 2> gpurun_out/$TAG/bench.err
@@ -13,3 +13,6 @@ for t in fetch write sq atomic; do python tools/pmc_summary.py gpurun_out/pmc_${
 timeout -k 10 300 python bench.py --no-cpu-baseline --rounds 5 > gpurun_out/$TAG/bench_rounds5.json 2>> gpurun_out/$TAG/bench.err
 cp $(find gpurun_out/$TAG/stats -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/kernel_stats_16M_256cube.csv
 echo done
+# the reference's default noise: kernel trace of the steady state (400 steps before the trace would be better; the trace covers all)
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/stats_noise1 -- python3 bench.py --no-cpu-baseline --noise 1.0 > gpurun_out/$TAG/bench_noise1_under_rocprof.json 2>> gpurun_out/$TAG/rocprof.err
+cp $(find gpurun_out/$TAG/stats_noise1 -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/kernel_stats_16M_256cube_noise1.csv
