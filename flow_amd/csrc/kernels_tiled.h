@@ -24,7 +24,12 @@
 namespace mpm {
 
 // Tile shape in cells.
-constexpr int kTX = 8, kTY = 8, kTZ = 8;
+#ifndef FLOWMPM_TX
+#define FLOWMPM_TX 8
+#define FLOWMPM_TY 8
+#define FLOWMPM_TZ 8
+#endif
+constexpr int kTX = FLOWMPM_TX, kTY = FLOWMPM_TY, kTZ = FLOWMPM_TZ;
 // Rim of the arena in cells: 1 is what the stencil of a freshly binned particle needs; every
 // cell beyond that is drift a stale bin tolerates before its particle falls back to global atomics.
 #ifndef FLOWMPM_RIM
@@ -38,8 +43,11 @@ constexpr int kArenaPad = kArenaCells + 8;     // component stride in LDS (dword
 // binning from the particle count (choose_chunk): a large scene gets the upper bound, where the arena's
 // set-up and flush are amortised best; a small one gets more, smaller items, so that the chip is filled
 // (several workgroups per tile merge through the same integer atomics: bits do not change).
-constexpr int kChunkMax = 4096, kChunkMin = 256;
-constexpr int kTiledThreads = 256;
+#ifndef FLOWMPM_TILED_THREADS
+#define FLOWMPM_TILED_THREADS 256
+#endif
+constexpr int kTiledThreads = FLOWMPM_TILED_THREADS;
+constexpr int kChunkMax = 16 * kTiledThreads, kChunkMin = kTiledThreads;
 // Minimum waves per SIMD the register allocator must leave room for (second argument of
 // __launch_bounds__) in the two register-heavy kernels; measured, not guessed.
 #ifndef FLOWMPM_P2G_WAVES
@@ -1355,9 +1363,9 @@ __device__ __forceinline__ bool tile_always(int tile, TileDims td, TileRange r)
 __device__ __forceinline__ long long tile_cell(int tile, int k, TileDims td, const Params &P, int *lx, int *y, int *z)
 {
     const int tz = tile % td.tiles_z, ty = (tile / td.tiles_z) % td.tiles_y, tx = tile / (td.tiles_z * td.tiles_y);
-    *z = tz * kTZ + (k & 7);
-    *y = ty * kTY + ((k >> 3) & 7);
-    *lx = tx * kTX + (k >> 6);
+    *z = tz * kTZ + k % kTZ;
+    *y = ty * kTY + (k / kTZ) % kTY;
+    *lx = tx * kTX + k / (kTZ * kTY);
     if (*lx >= P.local_nx || *y >= P.gy || *z >= P.gz) return -1;
     return ((long long)*lx * P.gy + *y) * P.gz + *z;
 }
