@@ -894,6 +894,98 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
         }
 }
 
+// Experiment (-DFLOWMPM_WAVE_REDUCE=1, tools/exp_wave_reduce.py): a segmented reduction over the wave in
+// front of the LDS atomics.  Lanes that hold particles of the same cell add to the same 27 x 3 words; with
+// the particles ordered by cell inside a tile such lanes are neighbours, and their already ENCODED words
+// (integers: regrouping is exact) are summed with DPP row shifts first, so that only the first lane of a
+// run issues the atomic.  A run ends at a change of cell and at every 16th lane (a DPP row).
+#ifndef FLOWMPM_WAVE_REDUCE
+#define FLOWMPM_WAVE_REDUCE 0
+#endif
+#if FLOWMPM_WAVE_REDUCE
+struct SegMasks { unsigned m[4]; bool head; };
+
+// row_shl:D -- lane i reads lane i + D of its row of 16, 0 past the end of the row
+template <int D>
+__device__ __forceinline__ int row_from_above(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + D, 0xF, 0xF, true); }
+
+// seg: the same positive number on lanes of one cell, a distinct negative one on lanes that take no part
+__device__ __forceinline__ SegMasks seg_masks(int seg)
+{
+    SegMasks r;
+    // m[k]: lanes i .. i + 2^k all hold the same cell (an equal cell further up behind a different one
+    // belongs to another run, which has a first lane of its own)
+    r.m[0] = row_from_above<1>(seg) == seg ? ~0u : 0u;
+    r.m[1] = r.m[0] & (unsigned)row_from_above<1>((int)r.m[0]);
+    r.m[2] = r.m[1] & (unsigned)row_from_above<2>((int)r.m[1]);
+    r.m[3] = r.m[2] & (unsigned)row_from_above<4>((int)r.m[2]);
+    r.head = __builtin_amdgcn_update_dpp(0, seg, 0x111, 0xF, 0xF, true) != seg;      // row_shr:1
+    return r;
+}
+
+__device__ __forceinline__ int seg_reduce(int v, const SegMasks &sm)
+{
+    v = add_wrap(v, (int)((unsigned)row_from_above<1>(v) & sm.m[0]));
+    v = add_wrap(v, (int)((unsigned)row_from_above<2>(v) & sm.m[1]));
+    v = add_wrap(v, (int)((unsigned)row_from_above<4>(v) & sm.m[2]));
+    v = add_wrap(v, (int)((unsigned)row_from_above<8>(v) & sm.m[3]));
+    return v;
+}
+
+// p2g_momentum_particle<true> for every lane of the wave at once; `inside` lanes are the ones that count
+__device__ __forceinline__ void p2g_momentum_particle_reduced(const Stencil &s, float vx, float vy, float vz,
+                                                              const float C[9], const float *dens_slot,
+                                                              float *dens_out, int *lds, const float *mass_f,
+                                                              int abase, bool inside, const SegMasks &sm,
+                                                              const Params &P)
+{
+    float density = 0.0f;
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++)
+                density = density + mass_f[abase + arena_index(gx, gy, gz)] * (wxy * s.wz[gz]);
+        }
+    if (inside) *dens_out = *dens_slot * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
+    Eq16 e = p2g2_stress(density, C, P);
+    const bool issue = inside && sm.head;
+#pragma unroll
+    for (int gx = 0; gx < 3; gx++)
+#pragma unroll
+        for (int gy = 0; gy < 3; gy++) {
+            float wxy = s.wx[gx] * s.wy[gy];
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                float weight = wxy * s.wz[gz];
+                float dx = s.dx[gx], dy = s.dy[gy], dz = s.dz[gz];
+                float qx = (C[0] * dx + C[3] * dy) + C[6] * dz;
+                float qy = (C[1] * dx + C[4] * dy) + C[7] * dz;
+                float qz = (C[2] * dx + C[5] * dy) + C[8] * dz;
+                int ex = encode_fixed(weight * (vx + qx));
+                int ey = encode_fixed(weight * (vy + qy));
+                int ez = encode_fixed(weight * (vz + qz));
+                float a00 = e.m00 * weight, a11 = e.m11 * weight, a22 = e.m22 * weight;
+                float a01 = e.m01 * weight, a02 = e.m02 * weight, a12 = e.m12 * weight;
+                ex = add_wrap(ex, encode_fixed((a00 * dx + a01 * dy) + a02 * dz));
+                ey = add_wrap(ey, encode_fixed((a01 * dx + a11 * dy) + a12 * dz));
+                ez = add_wrap(ez, encode_fixed((a02 * dx + a12 * dy) + a22 * dz));
+                ex = seg_reduce(inside ? ex : 0, sm);
+                ey = seg_reduce(inside ? ey : 0, sm);
+                ez = seg_reduce(inside ? ez : 0, sm);
+                if (issue) {
+                    int a = abase + arena_index(gx, gy, gz);
+                    atomicAdd(&lds[0 * kArenaPad + a], ex);
+                    atomicAdd(&lds[1 * kArenaPad + a], ey);
+                    atomicAdd(&lds[2 * kArenaPad + a], ez);
+                }
+            }
+        }
+}
+#endif
+
 __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_P2G_WAVES)
 p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
@@ -919,6 +1011,24 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     stamp.begin();
     // Software pipeline: the next particle's 15 loads are issued before this particle's LDS
     // atomics and density store, so an iteration never starts by waiting on memory.
+#if FLOWMPM_WAVE_REDUCE
+    // every lane of the wave takes every trip, so that the row shifts see all 64 lanes
+    for (int j0 = item.y; j0 < item.z; j0 += kTiledThreads) {
+        const int j = j0 + threadIdx.x;
+        const bool live = j < item.z;
+        float in[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) in[k] = live ? st.slot(kPosX + k)[j] : 2.0f;
+        Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
+        int abase;
+        const bool inside = stencil_in_arena(s, A, &abase) && live;
+        if (live && !inside) add_straggler(sg, sb, j);
+        if (!inside) abase = 0;
+        const SegMasks sm = seg_masks(inside ? abase + 1 : -1 - (int)(threadIdx.x & 63));
+        p2g_momentum_particle_reduced(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + (live ? j : item.y),
+                                      dens_out + (live ? ride.slot(j) : 0), lds, mass_f, abase, inside, sm, P);
+    }
+#else
     float in[15];
     int j = item.y + threadIdx.x;
     if (j < item.z) {
@@ -952,6 +1062,7 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 #endif
         j = jn;
     }
+#endif
     stamp.end(0);
     straggler_buf_flush(sg, sb);
     __syncthreads();
