@@ -1579,18 +1579,19 @@ inline void tiled_free(TiledState &T)
 #endif
 constexpr unsigned kBinBlocks = FLOWMPM_BIN_BLOCKS;
 
-// Work-item size for a binning of n particles: about kItemsPerCU items of full size per compute unit,
-// in multiples of the workgroup size, within [kChunkMin, kChunkMax].
-#ifndef FLOWMPM_ITEMS_PER_CU
-#define FLOWMPM_ITEMS_PER_CU 8
-#endif
+// Work-item size for a binning of n particles.  Measured (profiles/r02_chunk_sweep.txt): splitting a tile
+// over more, smaller work items to fill the chip makes small scenes SLOWER -- every item pays for its
+// arena (zeroing, the mass words, the flush), and that, not idle compute units, is what a small scene
+// spends its time on (2^20 particles / 128^3: 4096 -> 5.51e9/s, 512 -> 4.94, 256 -> 3.85).  So the
+// upper bound is the default; FLOWMPM_CHUNK sets another size (a multiple of the workgroup size) for
+// experiments.
 inline int choose_chunk(long long n)
 {
-    int per_cu = FLOWMPM_ITEMS_PER_CU;
-    if (const char *env = getenv("FLOWMPM_ITEMS_PER_CU")) per_cu = std::max(1, atoi(env));
-    const long long want = n / (256LL * per_cu);
-    const long long rounded = (want + kTiledThreads - 1) / kTiledThreads * kTiledThreads;
-    return (int)std::min<long long>(kChunkMax, std::max<long long>(kChunkMin, rounded));
+    (void)n;
+    int chunk = kChunkMax;
+    if (const char *env = getenv("FLOWMPM_CHUNK")) chunk = atoi(env);
+    chunk = (chunk + kTiledThreads - 1) / kTiledThreads * kTiledThreads;
+    return std::min(kChunkMax, std::max(kChunkMin, chunk));
 }
 
 // Enqueues the start-of-step pair of launches (see "binning" above).  When a re-bin is due the
