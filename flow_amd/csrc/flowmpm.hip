@@ -85,8 +85,9 @@ struct flowmpm_sim {
     int drift_divisor = 256;      // re-bin when (particles outside their arena) * divisor > particles
     // flowmpm_step of a single-domain handle on the two-pass tiled algorithm lets a re-bin ride on the
     // step's own stores (mpm::RebinCtl::riding) instead of moving every record once more
-    // (FLOWMPM_RIDE_REBINS=0 switches that off, for A/B runs).
-    bool ride_rebins = false;
+    // 2: the step's mass pass also counts the tiles; 1: a counting launch of its own; 0: off, the
+    // standalone two-launch re-bin (FLOWMPM_RIDE_REBINS sets it, for A/B runs).
+    int ride_rebins = 0;
     int4 *cell = nullptr;        // momentum words (word 3 unused on the device)
     int *mass_i = nullptr;       // mass words, one per cell
     // The float grid is non-zero only where this buffer is positive: the mass words of the step
@@ -487,7 +488,7 @@ int stage_rebin_if_needed(flowmpm_sim *s, bool ride)
     if (rc) return rc;
     std::string msg;
     if (mpm::rebin_if_due(T, s->store, s->live, s->params, s->cfg.rebin_interval, s->drift_divisor, s->stream,
-                          t.start, t.stop, &msg, ride && s->ride_rebins))
+                          t.start, t.stop, &msg, ride ? s->ride_rebins : 0))
         return fail(s, FLOWMPM_ERR_HIP, "rebin: " + msg);
     return FLOWMPM_OK;
 }
@@ -699,8 +700,9 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
             // it pays to carry more of them for longer (measured on slabs of the 8-slab decomposition
             // of 2^27 particles: 256 -> 2.57, 96 -> 2.44, 48 -> 2.34, 24 -> 2.35, 12 -> 2.36 ms per step).
             if (s->slab) s->drift_divisor = 48;
-            s->ride_rebins = !s->slab && c.algorithm == FLOWMPM_ALGO_TILED;
-            if (const char *env = getenv("FLOWMPM_RIDE_REBINS")) s->ride_rebins = s->ride_rebins && atoi(env) != 0;
+            s->ride_rebins = (!s->slab && c.algorithm == FLOWMPM_ALGO_TILED) ? 2 : 0;
+            if (const char *env = getenv("FLOWMPM_RIDE_REBINS"))
+                s->ride_rebins = s->ride_rebins ? std::min(2, std::max(0, atoi(env))) : 0;
             // A riding re-bin costs half of a standalone one, and the step it rides on still runs on the old
             // binning: it pays to start it earlier (steady state of the benchmark scene, noise uniform 0 / 1:
             // divisor 256 -> 10.17 / 7.78e9 per second, 512 -> 10.24 / 7.98, 1024 -> 10.22 / 7.98, 2048 -> 10.28 / 8.04).

@@ -140,6 +140,7 @@ struct RebinCtl {
     // the next item set; the momentum pass and g2p of the same step then store what they store anyway
     // into the particle's slot of the OTHER store, and the last workgroup of the step commits.
     int riding;      // latched by the step's binning launch: this step's stores go to the other store
+                     // (1: that launch counted the tiles, 2: the step's mass pass counts them)
     int drift_next;  // particles g2p leaves outside the arena of their NEW tile during a riding re-bin
     int item_set;    // which of the two item sets (work items, tile_start) is current
 };
@@ -161,6 +162,10 @@ struct TiledState {
     int *straggler_counts = nullptr;   // two device scalars used by alternate stages
     int *straggler_list = nullptr;
     int chunk = kChunkMax;       // particles per work item of the current binning (choose_chunk)
+    // A riding re-bin whose tiles the coming mass pass counts: the launch that builds the next item set
+    // follows that pass (launch_p2g_mass_tiled), timed with these events.
+    bool scan_after_mass = false;
+    hipEvent_t scan_ev_start = nullptr, scan_ev_stop = nullptr;
     int stage_parity = 0;        // which of the two the next stage counts into
     // The counter (0 / 1) under which the last momentum pass or p2g2 listed its stragglers, while the
     // particles are still the ones it saw, in the same slots; -1 otherwise.  g2p then reuses the list.
@@ -178,8 +183,11 @@ struct TiledWork {
     const int4 *items;           // both sets (TiledState)
     const int *n_items;
     long long item_cap;
-    // of the re-bin in flight (read only while RebinCtl::riding is set)
-    const int *key, *rank, *tile_start;
+    // of the re-bin in flight (touched only while RebinCtl::riding is set): the mass pass of the step
+    // writes key and rank and counts the tiles, the momentum pass and g2p read them
+    int *key, *rank;
+    int *tile_count;
+    const int *tile_start;
     int n_tiles;
     RebinCtl *ctl;
     int n;                       // live particles: items are clipped to [0, n)
@@ -240,17 +248,17 @@ __device__ __forceinline__ bool last_workgroup(int *ticket)
 }
 
 // Exclusive scan of the tile counts into tile_start plus the list of work items (runs of at
-// most kChunk particles of one tile), by one workgroup of 256 threads; leaves the counts zero
+// most kChunk particles of one tile), by one workgroup of 256 to 1024 threads; leaves the counts zero
 // for the next re-bin.  The counts were produced by device-scope atomics of other workgroups
 // of the same launch, hence the device-scope loads.
 __device__ __forceinline__ void scan_tiles(int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
                                            int4 *__restrict__ items, int *__restrict__ n_items_out,
                                            long long item_cap, const int kChunk)
 {
-    __shared__ int wave_cnt[4], wave_itm[4];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ int wave_cnt[16], wave_itm[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n_waves = (int)blockDim.x >> 6;
     int carry_cnt = 0, carry_itm = 0;
-    for (int base = 0; base < n_tiles; base += 4 * 256) {
+    for (int base = 0; base < n_tiles; base += 4 * (int)blockDim.x) {
         const int i0 = base + 4 * t;
         int c[4], m[4];
 #pragma unroll
@@ -270,8 +278,8 @@ __device__ __forceinline__ void scan_tiles(int *__restrict__ tile_count, int n_t
         __syncthreads();
         int start = carry_cnt + inc_cnt - my_cnt, first_item = carry_itm + inc_itm - my_itm;
         for (int v = 0; v < wave; v++) { start += wave_cnt[v]; first_item += wave_itm[v]; }
-        const int chunk_cnt = (wave_cnt[0] + wave_cnt[1]) + (wave_cnt[2] + wave_cnt[3]);
-        const int chunk_itm = (wave_itm[0] + wave_itm[1]) + (wave_itm[2] + wave_itm[3]);
+        int chunk_cnt = 0, chunk_itm = 0;
+        for (int v = 0; v < n_waves; v++) { chunk_cnt += wave_cnt[v]; chunk_itm += wave_itm[v]; }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int i = i0 + q;
@@ -381,6 +389,34 @@ bin_scatter_kernel(StoreSel ss, int n, const int *__restrict__ key, const int *_
         ctl->t_start = ~0ULL;
     }
 }
+
+// A riding re-bin needs no counting launch of its own: the mass pass of the step reads every position
+// anyway, and a work item's particles have moved, if at all, into one of the 26 tiles around their own --
+// so a workgroup counts them in 27 LDS words and takes its share of the global tile counters with at
+// most 27 atomics.  ride_decide_kernel (one lane) latches the decision before the mass pass,
+// ride_scan_kernel (one workgroup) turns the counts into the next item set after it.
+__global__ void ride_decide_kernel(RebinCtl *ctl, int n, int interval, int divisor)
+{
+    if (threadIdx.x != 0) return;
+    const bool due = rebin_due(ctl, n, interval, 0, divisor);
+    ctl->riding = due ? 2 : 0;      // 2: the mass pass counts the tiles
+}
+
+__global__ void __launch_bounds__(1024)
+ride_scan_kernel(RebinCtl *ctl, int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
+                 int4 *__restrict__ items, int *__restrict__ n_items_out, long long item_cap, int chunk)
+{
+    if (ctl->riding != 2) return;
+    const unsigned long long t0 = wall_clock64();
+    const int next_set = ctl->item_set ^ 1;
+    scan_tiles(tile_count, n_tiles, tile_start + (long long)next_set * (n_tiles + 1), items + (long long)next_set * item_cap,
+               n_items_out + next_set, item_cap, chunk);
+    if (threadIdx.x == 0) ctl->busy_ticks += (unsigned long long)wall_clock64() - t0;
+}
+
+// rank[] entries between the two passes of a counting mass pass
+constexpr int kRankNotMine = 0x7FFFFFFF;       // a straggler: the follow-up kernel ranks it
+constexpr int kRankNbShift = 24;               // (neighbour index << 24) | rank inside this workgroup's count
 
 // ---- arena helpers ---------------------------------------------------------------
 
@@ -800,15 +836,33 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     const Stragglers sg = w.sg;
     __shared__ int lds[kArenaCells];
     __shared__ StragglerBuf sb;
+    __shared__ int nb_count[27], nb_base[27];
     straggler_buf_init(sb);
     const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < kArenaCells; i += kTiledThreads) lds[i] = 0;
+    // counting for a riding re-bin (uniform over the launch)
+    const bool counting = w.ctl->riding == 2;
+    const int tz0 = item.x % w.td.tiles_z, ty0 = (item.x / w.td.tiles_z) % w.td.tiles_y,
+              tx0 = item.x / (w.td.tiles_z * w.td.tiles_y);
+    if (threadIdx.x < 27) nb_count[threadIdx.x] = 0;
     __syncthreads();
     // The tiles this work item adds to, for clearGrid and updateGrid (FixedGrid::dirty).  The
     // momentum pass scatters the same particles over the same cells and marks nothing.
     unsigned touched = 0;
     for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
         Stencil s = make_stencil(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j]);
+        if (counting) {
+            int abase_unused;
+            if (!stencil_in_arena(s, A, &abase_unused)) {
+                w.rank[j] = kRankNotMine;
+            } else {
+                // tile of floor(position) = s.c + 1; inside the arena it is this tile or one next to it
+                const int kx = (s.cx + 1 - P.x_off) / kTX, ky = (s.cy + 1) / kTY, kz = (s.cz + 1) / kTZ;
+                const int nb = ((kx - tx0 + 1) * 3 + (ky - ty0 + 1)) * 3 + (kz - tz0 + 1);
+                w.key[j] = (kx * w.td.tiles_y + ky) * w.td.tiles_z + kz;
+                w.rank[j] = (nb << kRankNbShift) | atomicAdd(&nb_count[nb], 1);
+            }
+        }
         if (s.cx + 1 < w.keep_lo || s.cx + 1 >= w.keep_hi) continue;       // s.cx = floor(x) - 1
         int abase;
         if (stencil_in_arena(s, A, &abase)) {
@@ -826,6 +880,18 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         if (c >= 0) atomicAdd(g.mass + c, v);
     }
     mark_dirty_tiles(touched, item.x, w.td, g);
+    if (!counting) return;                                   // uniform
+    // this workgroup's share of the 27 tile counters, then the ranks become ranks inside the tile
+    if (threadIdx.x < 27 && nb_count[threadIdx.x] > 0) {
+        const int nb = threadIdx.x;
+        const int tile = ((tx0 + nb / 9 - 1) * w.td.tiles_y + (ty0 + (nb / 3) % 3 - 1)) * w.td.tiles_z + (tz0 + nb % 3 - 1);
+        nb_base[nb] = atomicAdd(&w.tile_count[tile], nb_count[nb]);
+    }
+    __syncthreads();
+    for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
+        const int r = w.rank[j];
+        if (r != kRankNotMine) w.rank[j] = nb_base[r >> kRankNbShift] + (r & ((1 << kRankNbShift) - 1));
+    }
 }
 
 template <bool INSIDE>
@@ -1332,6 +1398,12 @@ straggler_p2g_team_kernel(TiledWork w, FixedGrid g, Params P)
         }
         if (!MOMENTUM) {
             if (cell >= 0) atomicAdd(g.mass + cell, encode_fixed(weight));
+            // a riding re-bin counts in the mass pass: the particles the tiled kernel left to this one
+            if (live && c == 0 && w.ctl->riding == 2) {
+                const int k = tile_of(px, py, pz, P, w.td);
+                w.key[j] = k;
+                w.rank[j] = atomicAdd(&w.tile_count[k], 1);
+            }
             continue;
         }
         float vx = 0.0f, vy = 0.0f, vz = 0.0f, C[9];
@@ -1602,17 +1674,29 @@ inline int choose_chunk(long long n)
 // the g2p stage of the same step, which must follow (flowmpm_step's order): they store what they store
 // anyway into the other store, at the particle's new slot, so the records are not moved a second time.
 // A forced re-bin (new particles: no binning to run the step's first passes on) never rides.
+// ride: 0 no; 1 the counting launch of its own; 2 the mass pass of the step counts (it must be the next
+// tiled stage: launch_p2g_mass_tiled then enqueues the launch that builds the next item set).
 inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P, int interval, int divisor,
                         hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, std::string *msg,
-                        bool ride = false)
+                        int ride = 0)
 {
     const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, kBinBlocks);
     const int force = T.valid ? 0 : 1;
     if (force) {
-        ride = false;
+        ride = 0;
         T.chunk = choose_chunk(n);      // kept until the next forced re-bin: the launch bounds rely on it
     }
     T.listed = -1;
+    if (ride == 2) {
+        hipLaunchKernelGGL(ride_decide_kernel, dim3(1), dim3(64), 0, stream, T.ctl, (int)n, interval, divisor);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) { *msg = std::string("ride_decide launch: ") + hipGetErrorString(e2); return 1; }
+        T.scan_after_mass = true;
+        T.scan_ev_start = ev_start;
+        T.scan_ev_stop = ev_stop;
+        T.checked = true;
+        return 0;
+    }
     hipExtLaunchKernelGGL(bin_count_scan_kernel, dim3(blocks), dim3(256), 0, stream, ev_start, ride ? ev_stop : nullptr,
                           0, ss, (int)n, P, tile_dims(T), T.key, T.rank, T.tile_count, T.n_tiles, T.tile_start, T.items,
                           T.n_items, T.item_cap, T.ctl, interval, force, divisor, ride ? 1 : 0, T.chunk);
@@ -1639,7 +1723,7 @@ inline TiledWork tiled_work(TiledState &T, StoreSel ss, long long n, StagePart s
     const Stragglers sg{T.straggler_counts + T.stage_parity, T.straggler_counts + (T.stage_parity ^ 1),
                         T.straggler_list};
     if (sp.part != 1) T.stage_parity ^= 1;
-    return TiledWork{ss, T.items, T.n_items, T.item_cap, T.key, T.rank, T.tile_start, T.n_tiles, T.ctl, (int)n,
+    return TiledWork{ss, T.items, T.n_items, T.item_cap, T.key, T.rank, T.tile_count, T.tile_start, T.n_tiles, T.ctl, (int)n,
                      tile_dims(T), sg, -2147483647 - 1, 2147483647, sp.part, sp.bnd_lo, sp.bnd_hi};
 }
 
@@ -1689,6 +1773,11 @@ inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedG
     hipExtLaunchKernelGGL(p2g_mass_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, ev_start,
                           ev_stop, 0, w, g, P);
     hipLaunchKernelGGL(straggler_p2g_team_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
+    if (T.scan_after_mass) {
+        T.scan_after_mass = false;
+        hipExtLaunchKernelGGL(ride_scan_kernel, dim3(1), dim3(1024), 0, stream, T.scan_ev_start, T.scan_ev_stop, 0, T.ctl,
+                              T.tile_count, T.n_tiles, T.tile_start, T.items, T.n_items, T.item_cap, T.chunk);
+    }
     return 0;
 }
 
