@@ -598,6 +598,16 @@ struct Ride {
     __device__ __forceinline__ int slot(int j) const { return on ? start[key[j]] + rank[j] : j; }
 };
 
+// The columns no stage of the step writes, from slot j of the current store to slot d of the other.
+__device__ __forceinline__ void ride_carry_constants(const Store &src, const Store &dst, int j, int d)
+{
+    dst.slot(kMass)[d] = src.slot(kMass)[j];
+    dst.slot(kColR)[d] = src.slot(kColR)[j];
+    dst.slot(kColG)[d] = src.slot(kColG)[j];
+    dst.slot(kColB)[d] = src.slot(kColB)[j];
+    dst.ids()[d] = src.ids()[j];
+}
+
 __device__ __forceinline__ Ride ride_of(const TiledWork &w, const Store &cur)
 {
     const bool on = w.ctl->riding != 0;
@@ -968,6 +978,12 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
 #ifndef FLOWMPM_WAVE_REDUCE
 #define FLOWMPM_WAVE_REDUCE 0
 #endif
+// Which kernel carries the columns no stage writes (mass, colour, id) to the particle's new slot while
+// a re-bin rides on the step: 1 the momentum pass (bound by LDS and VALU, with memory bandwidth to
+// spare), 0 g2p.
+#ifndef FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
+#define FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM 1
+#endif
 #if FLOWMPM_WAVE_REDUCE
 struct SegMasks { unsigned m[4]; bool head; };
 
@@ -1089,6 +1105,9 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         int abase;
         const bool inside = stencil_in_arena(s, A, &abase) && live;
         if (live && !inside) add_straggler(sg, sb, j);
+#if FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
+        if (live && ride.on) ride_carry_constants(st, ride.dst, j, ride.slot(j));
+#endif
         if (!inside) abase = 0;
         const SegMasks sm = seg_masks(inside ? abase + 1 : -1 - (int)(threadIdx.x & 63));
         p2g_momentum_particle_reduced(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + (live ? j : item.y),
@@ -1112,9 +1131,13 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 #endif
         Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
         int abase;
+        const int d = ride.slot(j);
+#if FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
+        if (ride.on) ride_carry_constants(st, ride.dst, j, d);      // stragglers included: every slot of the run
+#endif
         if (stencil_in_arena(s, A, &abase))
             p2g_momentum_particle<true>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + j,
-                                        dens_out + ride.slot(j), lds, mass_f, abase, g, P);
+                                        dens_out + d, lds, mass_f, abase, g, P);
         else
             add_straggler(sg, sb, j);
 #if FLOWMPM_PREFETCH_P2G
@@ -1293,11 +1316,9 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
                 const int tile = ride.key[j];
                 d = ride.start[tile] + ride.rank[j];
                 An = arena_of_tile(tile, w.td, P);
-                out.slot(kMass)[d] = st.slot(kMass)[j];
-                out.slot(kColR)[d] = st.slot(kColR)[j];
-                out.slot(kColG)[d] = st.slot(kColG)[j];
-                out.slot(kColB)[d] = st.slot(kColB)[j];
-                out.ids()[d] = st.ids()[j];
+#if !FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
+                ride_carry_constants(st, out, j, d);
+#endif
             }
 #pragma unroll
             for (int k = 0; k < 9; k++) out.slot(kC00 + k)[d] = o.C[k];
@@ -1493,11 +1514,9 @@ straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
             const int tile = ride.key[j];
             d = ride.start[tile] + ride.rank[j];
             const Arena An = arena_of_tile(tile, w.td, P);
-            out.slot(kMass)[d] = st.slot(kMass)[j];
-            out.slot(kColR)[d] = st.slot(kColR)[j];
-            out.slot(kColG)[d] = st.slot(kColG)[j];
-            out.slot(kColB)[d] = st.slot(kColB)[j];
-            out.ids()[d] = st.ids()[j];
+#if !FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
+            ride_carry_constants(st, out, j, d);
+#endif
             const int bx = f32_to_i32(o.px) - 1 - An.ox, by = f32_to_i32(o.py) - 1 - An.oy,
                       bz = f32_to_i32(o.pz) - 1 - An.oz;
             drifted += !((unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
