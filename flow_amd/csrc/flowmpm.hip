@@ -706,7 +706,9 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
             // A riding re-bin costs half of a standalone one, and the step it rides on still runs on the old
             // binning: it pays to start it earlier (steady state of the benchmark scene, noise uniform 0 / 1:
             // divisor 256 -> 10.17 / 7.78e9 per second, 512 -> 10.24 / 7.98, 1024 -> 10.22 / 7.98, 2048 -> 10.28 / 8.04).
-            if (s->ride_rebins) s->drift_divisor = 1024;
+            // With the count in the mass pass and the constant columns in the momentum pass (0.30 ms per re-bin):
+            // 1024 -> 10.22 / 8.38, 4096 -> 10.31 / 8.21, 8192 -> 10.35 / 8.45, 16384 -> 10.37 / 8.48.
+            if (s->ride_rebins) s->drift_divisor = 8192;
             if (const char *env = getenv("FLOWMPM_DRIFT_DIVISOR")) s->drift_divisor = atoi(env);
             HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->dirty), (size_t)s->tiled.n_tiles * sizeof(int)));
             HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
@@ -1076,6 +1078,18 @@ int flowmpm_debug_clock_stamps(flowmpm_sim *s, int32_t kernel, uint64_t *out, in
     HIP_TRY(s, hipStreamSynchronize(s->stream));
     HIP_TRY(s, hipMemcpyFromSymbol(out, HIP_SYMBOL(mpm::g_clock_stamps), (size_t)slots * 2 * sizeof(uint64_t),
                                    (size_t)kernel * mpm::kStampSlots * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return FLOWMPM_OK;
+}
+
+// `slots` records of {set-up, particle loop, flush (100 MHz ticks), particles} per workgroup of `kernel`.
+int flowmpm_debug_phase_stamps(flowmpm_sim *s, int32_t kernel, uint32_t *out, int64_t slots)
+{
+    CHECK_SIM(s);
+    if (kernel < 0 || kernel > 1 || !out || slots < 1 || slots > mpm::kStampSlots)
+        return fail(s, FLOWMPM_ERR_INVALID, "bad stamp request");
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    HIP_TRY(s, hipMemcpyFromSymbol(out, HIP_SYMBOL(mpm::g_phase_stamps), (size_t)slots * 4 * sizeof(uint32_t),
+                                   (size_t)kernel * mpm::kStampSlots * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return FLOWMPM_OK;
 }
 #endif

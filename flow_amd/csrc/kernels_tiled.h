@@ -59,6 +59,9 @@ constexpr int kChunkMax = 16 * kTiledThreads, kChunkMin = kTiledThreads;
 #ifndef FLOWMPM_G2P_B128
 #define FLOWMPM_G2P_B128 0   // measured: 16-byte reads cost 8 VGPRs and 2% of g2p
 #endif
+#ifndef FLOWMPM_EXP_NO_SETUP
+#define FLOWMPM_EXP_NO_SETUP 0
+#endif
 #ifndef FLOWMPM_G2P_READ_ALL
 #define FLOWMPM_G2P_READ_ALL 0
 #endif
@@ -88,8 +91,14 @@ constexpr int kChunkMax = 16 * kTiledThreads, kChunkMin = kTiledThreads;
 #if FLOWMPM_STAMPS
 constexpr int kStampSlots = 1 << 15;
 __device__ unsigned long long g_clock_stamps[2][kStampSlots][2];      // [kernel][workgroup][shader, real]
+// phases of a workgroup in 100 MHz ticks: arena set-up, particle loop, flush; and its particle count
+__device__ unsigned int g_phase_stamps[2][kStampSlots][4];
 struct ClockStamp {
-    unsigned long long t0, r0;
+    unsigned long long t0, r0, enter;
+    __device__ __forceinline__ void entered()
+    {
+        if (threadIdx.x == 0) enter = __builtin_amdgcn_s_memrealtime();
+    }
     __device__ __forceinline__ void begin()
     {
         if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -101,11 +110,23 @@ struct ClockStamp {
             g_clock_stamps[kernel][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - r0;
         }
     }
+    __device__ __forceinline__ void left(int kernel, int particles)
+    {
+        if (threadIdx.x == 0 && blockIdx.x < (unsigned)kStampSlots) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            g_phase_stamps[kernel][blockIdx.x][0] = (unsigned)(r0 - enter);
+            g_phase_stamps[kernel][blockIdx.x][1] = (unsigned)g_clock_stamps[kernel][blockIdx.x][1];
+            g_phase_stamps[kernel][blockIdx.x][2] = (unsigned)(now - r0) - (unsigned)g_clock_stamps[kernel][blockIdx.x][1];
+            g_phase_stamps[kernel][blockIdx.x][3] = (unsigned)particles;
+        }
+    }
 };
 #else
 struct ClockStamp {
+    __device__ __forceinline__ void entered() {}
     __device__ __forceinline__ void begin() {}
     __device__ __forceinline__ void end(int) {}
+    __device__ __forceinline__ void left(int, int) {}
 };
 #endif
 
@@ -1075,21 +1096,37 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     int4 item;
     if (!take_item(w, &item)) return;
     const Stragglers sg = w.sg;
+    ClockStamp stamp;
+    stamp.entered();
     __shared__ int lds[3 * kArenaPad];
     __shared__ float mass_f[kArenaCells];
     __shared__ StragglerBuf sb;
     straggler_buf_init(sb);
     const Arena A = arena_of_tile(item.x, w.td, P);
+    // (Requesting the first particles together with the arena, as g2p does, was measured here too:
+    // the registers it takes at the top of the kernel cost the pass its fifth wave per SIMD, or spills,
+    // and the set-up's round trips are already covered by the other workgroups of the compute unit.)
     for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
+#if FLOWMPM_EXP_NO_SETUP      // timing experiment only (wrong results): what the arena loads cost
+        mass_f[a] = 1.0f;
+#else
         long long c = arena_cell_to_grid(a, A, P);
         mass_f[a] = decode_fixed((c >= 0) ? g.mass[c] : 0);
+#endif
     }
     __syncthreads();
     const Column<float> dens = st.slot(kDensity);
     const Ride ride = ride_of(w, st);
     const Column<float> dens_out = ride.dst.slot(kDensity);
-    ClockStamp stamp;
+#if !FLOWMPM_WAVE_REDUCE
+    float in[15];
+    int j = item.y + threadIdx.x;
+    if (j < item.z) {
+#pragma unroll
+        for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
+    }
+#endif
     stamp.begin();
     // Software pipeline: the next particle's 15 loads are issued before this particle's LDS
     // atomics and density store, so an iteration never starts by waiting on memory.
@@ -1114,12 +1151,6 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
                                       dens_out + (live ? ride.slot(j) : 0), lds, mass_f, abase, inside, sm, P);
     }
 #else
-    float in[15];
-    int j = item.y + threadIdx.x;
-    if (j < item.z) {
-#pragma unroll
-        for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
-    }
     while (j < item.z) {
         const int jn = j + kTiledThreads;
 #if FLOWMPM_PREFETCH_P2G
@@ -1156,6 +1187,11 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     straggler_buf_flush(sg, sb);
     __syncthreads();
     flush_arena<3>(lds, A, P, g);
+#if FLOWMPM_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);      // the flush's atomics have been accepted
+    __syncthreads();
+#endif
+    stamp.left(0, item.z - item.y);
 }
 
 // ---- g2p (SIM:431-1536; MODES as in g2p_gather_kernel) ------------------------------
@@ -1250,13 +1286,29 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
     int4 item;
     if (!take_item(w, &item)) return;
     const Stragglers sg = w.sg;
+    ClockStamp stamp;
+    stamp.entered();
     __shared__ float4 grid[kArenaCells];
     const Arena A = arena_of_tile(item.x, w.td, P);
-    for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
-        long long c = arena_cell_to_grid(a, A, P);
-        grid[a] = (c >= 0) ? cellf[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // The arena's cells and the first particles are requested together, the arena first: loads return
+    // in order, so the arena can be written to LDS while the particle loads are still in flight, and a
+    // work item waits for memory once at its start, not twice (under load a round trip takes several
+    // microseconds, against about 50 for a whole work item).  0.617 -> 0.592 ms.
+    constexpr int kArenaPerThread = (kArenaCells + kTiledThreads - 1) / kTiledThreads;
+    float4 arena_raw[kArenaPerThread];
+#pragma unroll
+    for (int q = 0; q < kArenaPerThread; q++) {
+        const int a = threadIdx.x + q * kTiledThreads;
+        const long long c = a < kArenaCells ? arena_cell_to_grid(a, A, P) : -1;
+#if FLOWMPM_EXP_NO_SETUP
+        arena_raw[q] = make_float4(0.01f, 0.01f, 0.01f, 1.0f);
+#else
+        // always a load (of cell 0 for a cell outside the grid), then a select: a load under a branch is
+        // waited for at the end of the branch
+        const float4 v = cellf[c >= 0 ? c : 0];
+        arena_raw[q] = (c >= 0) ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#endif
     }
-    __syncthreads();
 
     // Software pipeline: the next particle's loads are issued before this particle's 18 stores
     // (the memory counter retires in order, so a load issued after them would wait for them).
@@ -1274,9 +1326,14 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
     int drifted = 0;    // particles this thread leaves outside the arena: stragglers of the next step
     const Ride ride = ride_of(w, st);
     const Store out = ride.dst;
-    ClockStamp stamp;
+    load(in, min(j, item.z - 1));          // unconditional, for the same reason
+#pragma unroll
+    for (int q = 0; q < kArenaPerThread; q++) {
+        const int a = threadIdx.x + q * kTiledThreads;
+        if (a < kArenaCells) grid[a] = arena_raw[q];
+    }
+    __syncthreads();
     stamp.begin();
-    if (j < item.z) load(in, j);
     while (j < item.z) {
         const int jn = j + kTiledThreads;
 #if FLOWMPM_PREFETCH_G2P
@@ -1340,6 +1397,10 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
         j = jn;
     }
     stamp.end(1);
+#if FLOWMPM_STAMPS
+    __syncthreads();
+#endif
+    stamp.left(1, item.z - item.y);
     if (__any(drifted != 0)) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) drifted += __shfl_down(drifted, off);

@@ -159,10 +159,12 @@ def test_long_run_on_one_binning(oracle_binding, monkeypatch, case):
     h.close()
 
 
-def test_g2p_lists_its_own_stragglers_when_no_momentum_pass_did(oracle_binding):
+def test_g2p_lists_its_own_stragglers_when_no_momentum_pass_did(oracle_binding, monkeypatch):
     """g2p skips the particles outside their arena that the momentum pass (or p2g2) of the same
     step listed.  Run on its own -- here a second time on the same float grid, and once right
-    after the particles were replaced -- it has no such list and must build one."""
+    after the particles were replaced -- it has no such list and must build one.  (The drift rule is
+    off, so that no re-bin takes the stragglers away.)"""
+    monkeypatch.setenv("FLOWMPM_DRIFT_DIVISOR", "0")
     grid, n = (40, 24, 16), 6000
     rec = moving_particles(n, grid, seed=53, vel=3.0)
     h = _handle(grid, rec, _lib.ALGO_TILED, rebin_interval=100000)

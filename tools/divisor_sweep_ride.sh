@@ -4,7 +4,7 @@
 TAG=${1:-div}; shift
 mkdir -p gpurun_out/$TAG
 for noise in 0.0 1.0; do
-for div in 128 256 512 1024 2048; do
+for div in ${DIVS:-1024 2048 4096 8192 16384}; do
   FLOWMPM_DRIFT_DIVISOR=$div timeout -k 10 300 python -u bench.py --no-cpu-baseline --noise $noise "$@" > gpurun_out/$TAG/div_${div}_n$noise.json || exit 1
   python - gpurun_out/$TAG/div_${div}_n$noise.json $div $noise <<'PY'
 import json, sys
