@@ -1103,9 +1103,8 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     __shared__ StragglerBuf sb;
     straggler_buf_init(sb);
     const Arena A = arena_of_tile(item.x, w.td, P);
-    // (Requesting the first particles together with the arena, as g2p does, was measured here too:
-    // the registers it takes at the top of the kernel cost the pass its fifth wave per SIMD, or spills,
-    // and the set-up's round trips are already covered by the other workgroups of the compute unit.)
+    // (Requesting the first particles before or together with the arena, which gains g2p 4 %, was
+    // measured here too: no change when it costs no registers, and a wave per SIMD less when it does.)
     for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
 #if FLOWMPM_EXP_NO_SETUP      // timing experiment only (wrong results): what the arena loads cost
