@@ -707,3 +707,53 @@ def test_per_frame_reads_allocate_nothing_after_the_first():
             h.grid_sums()
     assert h.allocation_count() == before
     h.close()
+
+
+@pytest.mark.parametrize("form", ["0", "1", "2"], ids=["standalone", "own_count", "mass_pass_count"])
+def test_every_form_of_the_rebin_gives_the_same_bits(oracle_binding, monkeypatch, form):
+    """The re-bin of flowmpm_step exists in three forms (FLOWMPM_RIDE_REBINS): standalone, riding on the
+    step with a counting launch of its own, riding with the count in the mass pass.  Each must leave the
+    oracle's bits -- with a re-bin in every step, with the device deciding, with stages run one by one and
+    downloads in between, with the live count changed and with particles replaced while a binning exists."""
+    monkeypatch.setenv("FLOWMPM_RIDE_REBINS", form)
+    ob = oracle_binding
+    grid, n = (40, 24, 32), 9000
+    rec = moving_particles(n, grid, seed=61, vel=2.5)
+    u = ob.make_uniforms(grid, n, **DEFAULT_UNIFORMS)
+    for interval in (1, 3, 100000):
+        h = _handle(grid, rec, _lib.ALGO_TILED, rebin_interval=interval)
+        orc = ob.Oracle(grid, threads=4)
+        want = rec.copy()
+        h.step(5, 0.0)
+        orc.run(want, u, 5, 0.0)
+        assert_bits_equal(h.download_particles(), want, "form %s, interval %d: 5 steps" % (form, interval))
+        assert np.array_equal(h.download_grid_i32(), orc.cell)
+        # stage by stage (the standalone re-bin), then steps again
+        for kern in (_lib.KERNEL_CLEAR_GRID, _lib.KERNEL_P2G1, _lib.KERNEL_P2G2, _lib.KERNEL_UPDATE_GRID, _lib.KERNEL_G2P):
+            h.run_kernel(kern)
+        orc.step(want, u)
+        h.step(3, 0.0)
+        orc.run(want, u, 3, 0.0)
+        assert_bits_equal(h.download_particles(), want, "form %s, interval %d: stages, then steps" % (form, interval))
+        assert_bits_equal(h.download_grid_f32(), orc.cellf, "float grid")
+        # fewer live particles (the parked records keep their state), then all of them again
+        h.set_num_particles(5000)
+        h.step(2, 0.0)
+        orc.run(want, ob.make_uniforms(grid, 5000, **DEFAULT_UNIFORMS), 2, 0.0)
+        assert_bits_equal(h.download_particles(), want, "form %s, interval %d: 5000 live" % (form, interval))
+        h.set_num_particles(n)
+        h.step(2, 0.0)
+        orc.run(want, u, 2, 0.0)
+        assert_bits_equal(h.download_particles(), want, "form %s, interval %d: all live again" % (form, interval))
+        # the particles replaced while a binning exists
+        h.upload_particles(rec)
+        want = rec.copy()
+        h.step(4, 0.0)
+        orc.run(want, u, 4, 0.0)
+        assert_bits_equal(h.download_particles(), want, "form %s, interval %d: after a new upload" % (form, interval))
+        assert_bits_equal(h.download_field(_lib.FIELD_COLOR), want[:, 24:27], "colours travel with the records")
+        assert_bits_equal(h.download_field(_lib.FIELD_MASS)[:, 0], want[:, 7], "masses travel with the records")
+        t = h.timings()["rebin"]
+        if interval == 1:
+            assert t["performed"] >= 15, t
+        h.close()
