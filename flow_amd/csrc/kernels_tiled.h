@@ -59,6 +59,12 @@ constexpr int kChunkMax = 16 * kTiledThreads, kChunkMin = kTiledThreads;
 #ifndef FLOWMPM_G2P_B128
 #define FLOWMPM_G2P_B128 0   // measured: 16-byte reads cost 8 VGPRs and 2% of g2p
 #endif
+// Timing experiments only (WRONG results; tools/ablate.sh): bit 0 g2p's gather without its LDS reads,
+// bit 1 g2p without the noise field, bit 2 g2p without its stores, bit 3 the momentum pass without its LDS
+// atomics, bit 4 the momentum pass without the mass reads of its density sum.
+#ifndef FLOWMPM_ABLATE
+#define FLOWMPM_ABLATE 0
+#endif
 #ifndef FLOWMPM_EXP_NO_SETUP
 #define FLOWMPM_EXP_NO_SETUP 0
 #endif
@@ -942,7 +948,11 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
                 float weight = wxy * s.wz[gz];
                 float m;
                 if (INSIDE) {
+#if FLOWMPM_ABLATE & 16
+                    m = s.wx[gx];
+#else
                     m = mass_f[abase + arena_index(gx, gy, gz)];
+#endif
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     m = decode_fixed((c >= 0) ? g.mass[c] : 0);
@@ -976,9 +986,13 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
                 ez = add_wrap(ez, encode_fixed((a02 * dx + a12 * dy) + a22 * dz));
                 if (INSIDE) {
                     int a = abase + arena_index(gx, gy, gz);
+#if FLOWMPM_ABLATE & 8
+                    if (ex == 0x7ABCDEF1 && ey == 0x7ABCDEF2 && ez == a) lds[a] = 1;      // keeps the arithmetic alive
+#else
                     atomicAdd(&lds[0 * kArenaPad + a], ex);
                     atomicAdd(&lds[1 * kArenaPad + a], ey);
                     atomicAdd(&lds[2 * kArenaPad + a], ez);
+#endif
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     if (c >= 0) {
@@ -1237,6 +1251,8 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                 if (INSIDE) {
 #if FLOWMPM_G2P_READ_ALL
                     f = make_float4(fx[(gx * 3 + gy) * 3 + gz], fy[(gx * 3 + gy) * 3 + gz], fz[(gx * 3 + gy) * 3 + gz], 0.0f);
+#elif FLOWMPM_ABLATE & 1
+                    f = make_float4(s.wx[gx], s.wy[gy], s.wz[gz], 0.0f);
 #else
                     f = grid[abase + arena_index(gx, gy, gz)];
 #endif
@@ -1376,11 +1392,23 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
                 ride_carry_constants(st, out, j, d);
 #endif
             }
+#if FLOWMPM_ABLATE & 4       // no stores; the values stay alive
+#pragma unroll
+            for (int k = 0; k < 9; k++) asm volatile("" :: "v"(o.C[k]));
+            asm volatile("" :: "v"(o.px), "v"(o.py), "v"(o.pz), "v"(o.vx), "v"(o.vy), "v"(o.vz), "v"(o.dirx), "v"(o.diry), "v"(o.dirz));
+#elif FLOWMPM_ABLATE & 32    // half of the stores
+#pragma unroll
+            for (int k = 0; k < 9; k++) asm volatile("" :: "v"(o.C[k]));
+            out.slot(kPosX)[d] = o.px; out.slot(kPosY)[d] = o.py; out.slot(kPosZ)[d] = o.pz;
+            out.slot(kVelX)[d] = o.vx; out.slot(kVelY)[d] = o.vy; out.slot(kVelZ)[d] = o.vz;
+            out.slot(kDirX)[d] = o.dirx; out.slot(kDirY)[d] = o.diry; out.slot(kDirZ)[d] = o.dirz;
+#else
 #pragma unroll
             for (int k = 0; k < 9; k++) out.slot(kC00 + k)[d] = o.C[k];
             out.slot(kPosX)[d] = o.px; out.slot(kPosY)[d] = o.py; out.slot(kPosZ)[d] = o.pz;
             out.slot(kVelX)[d] = o.vx; out.slot(kVelY)[d] = o.vy; out.slot(kVelZ)[d] = o.vz;
             out.slot(kDirX)[d] = o.dirx; out.slot(kDirY)[d] = o.diry; out.slot(kDirZ)[d] = o.dirz;
+#endif
             const int bx = f32_to_i32(o.px) - 1 - An.ox, by = f32_to_i32(o.py) - 1 - An.oy,
                       bz = f32_to_i32(o.pz) - 1 - An.oz;
             drifted += !((unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
