@@ -65,6 +65,12 @@ constexpr int kChunkMax = 16 * kTiledThreads, kChunkMin = kTiledThreads;
 #ifndef FLOWMPM_ABLATE
 #define FLOWMPM_ABLATE 0
 #endif
+// Experiment (tools/exp_g2p_fma.py): g2p's affine sums B += (w g) (x) dist as fused multiply-adds.  The
+// fixed-point grid of a step does not depend on g2p, and the stated tolerance for particle state is 1e-5
+// relative, but the bits are no longer the reference's: never the default.
+#ifndef FLOWMPM_G2P_FMA
+#define FLOWMPM_G2P_FMA 0
+#endif
 #ifndef FLOWMPM_EXP_NO_SETUP
 #define FLOWMPM_EXP_NO_SETUP 0
 #endif
@@ -1268,11 +1274,19 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                 const Float2v wvxy = Float2v{f.x, f.y} * weight;
                 const float wvz = f.z * weight;
                 const float dz = s.dz[gz];
+#if FLOWMPM_G2P_FMA      // experiment: the nine affine sums contracted (NOT the reference's bits)
+                B01 = __builtin_elementwise_fma(wvxy, Float2v{dxy.x, dxy.x}, B01);
+                B34 = __builtin_elementwise_fma(wvxy, Float2v{dxy.y, dxy.y}, B34);
+                B67 = __builtin_elementwise_fma(wvxy, Float2v{dz, dz}, B67);
+                B25 = __builtin_elementwise_fma(Float2v{wvz, wvz}, dxy, B25);
+                B8 = __builtin_fmaf(wvz, dz, B8);
+#else
                 B01 = B01 + wvxy * dxy.x;
                 B34 = B34 + wvxy * dxy.y;
                 B67 = B67 + wvxy * dz;
                 B25 = B25 + wvz * dxy;
                 B8 = B8 + wvz * dz;
+#endif
                 vxy = vxy + wvxy;
                 vz = vz + wvz;
             }
