@@ -319,10 +319,13 @@ __device__ __forceinline__ void scan_tiles(int *__restrict__ tile_count, int n_t
             if (i < n_tiles) {
                 tile_start[i] = start;
                 tile_count[i] = 0;
+                // a tile that needs several items is cut into equal parts (in whole waves), not into full
+                // items and a remainder: every item pays for its arena, a small one as much as a full one
+                const int per = m[q] > 0 ? ((c[q] + m[q] - 1) / m[q] + 63) / 64 * 64 : 0;
                 for (int k = 0; k < m[q]; k++)
                     if (first_item + k < item_cap)
                         items[first_item + k] =
-                            make_int4(i, start + k * kChunk, min(start + (k + 1) * kChunk, start + c[q]), 0);
+                            make_int4(i, min(start + k * per, start + c[q]), min(start + (k + 1) * per, start + c[q]), 0);
                 start += c[q];
                 first_item += m[q];
             }
