@@ -68,6 +68,9 @@ def parse_args():
                     help="gloo = rehearsal of the multi-rank path on fewer GPUs than ranks (host-staged transport)")
     ap.add_argument("--slab-yz", type=int, default=512, help="y and z extent of the multi-GPU domain")
     ap.add_argument("--slab-x-per-gpu", type=int, default=64)
+    ap.add_argument("--one-slab", action="store_true",
+                    help="N=1 through the multi-GPU code path: one 64 x 512 x 512 slab, no neighbour (what one "
+                         "rank of the weak-scaling runs computes, without the exchanges)")
     return ap.parse_args()
 
 
@@ -373,6 +376,12 @@ def run_distributed(args):
     from flow_amd import _lib
     from flow_amd.slab import SlabSimulation, balanced_plane_starts
 
+    if args.one_slab and "WORLD_SIZE" not in os.environ:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        args.dist_backend = "gloo"          # nothing travels: the process group only answers world size 1
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     n_devices = max(torch.cuda.device_count(), 1)
     local_rank = int(os.environ.get("LOCAL_RANK", rank)) % n_devices
@@ -507,7 +516,7 @@ def main():
     if args.gpus > 1 and world_env is None:
         raise SystemExit(spawn_ranks(args.gpus))
     world = int(world_env or "1")
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.one_slab:
         if world != args.gpus:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)"
                              % (args.gpus, world))

@@ -160,7 +160,12 @@ struct RebinCtl {
     int ticket;      // workgroups of the running binning kernel that have finished
     int age;         // g2p stages since the last re-bin
     int cum_drift;   // sum over those stages of the particles left outside their arena
-    int binned;      // particles [0, binned) are covered by the work items
+    int binned;      // particles [0, binned) were there at the last re-bin (the rest arrived since)
+    // Particles [0, dense) are covered by the work items.  [dense, binned) are those of the tiles the last
+    // re-bin found nearly empty: a work item pays for its arena whatever it holds, a handful of particles
+    // is cheaper on the follow-up kernels' path (straight to the global grid), which takes every slot from
+    // `dense` on.  dense_next: of the binning a re-bin in flight is building.
+    int dense, dense_next;
     int rebins;      // re-bins performed since the counter was last cleared
     // Device time those re-bins took, in ticks of the constant-rate wall clock (from the first
     // workgroup of the first launch to the commit in the second), and the start of the one in flight.
@@ -195,9 +200,11 @@ struct TiledState {
     int *straggler_counts = nullptr;   // two device scalars used by alternate stages
     int *straggler_list = nullptr;
     int chunk = kChunkMax;       // particles per work item of the current binning (choose_chunk)
+    int sparse = 0;              // tiles with fewer particles get no work item (choose_sparse)
     // A riding re-bin whose tiles the coming mass pass counts: the launch that builds the next item set
     // follows that pass (launch_p2g_mass_tiled), timed with these events.
     bool scan_after_mass = false;
+    int ride_interval = 0, ride_divisor = 0;      // what that mass pass decides with (rebin_due)
     hipEvent_t scan_ev_start = nullptr, scan_ev_stop = nullptr;
     int stage_parity = 0;        // which of the two the next stage counts into
     // The counter (0 / 1) under which the last momentum pass or p2g2 listed its stragglers, while the
@@ -234,6 +241,9 @@ struct TiledWork {
     // (bnd_lo < tile x index < bnd_hi), part 2 the others; part 0 takes all.  A slab uses this to
     // run the items that cannot see its boundary planes while those planes' halo is in flight.
     int part, bnd_lo, bnd_hi;
+    // Mass pass only: decide != 0 makes it the launch that decides whether a re-bin rides on the step
+    // (rebin_due with these two) and latches the answer in RebinCtl::riding.
+    int decide, interval, divisor;
 };
 
 __device__ __forceinline__ int tile_of(float px, float py, float pz, const Params &P, TileDims td)
@@ -284,40 +294,50 @@ __device__ __forceinline__ bool last_workgroup(int *ticket)
 // most kChunk particles of one tile), by one workgroup of 256 to 1024 threads; leaves the counts zero
 // for the next re-bin.  The counts were produced by device-scope atomics of other workgroups
 // of the same launch, hence the device-scope loads.
+//
+// Tiles with fewer than `sparse` particles get no work item: their particles are placed at the end of
+// the store, [n - their number, n), the others from slot 0 on, and *dense_out receives the first slot of
+// that tail (RebinCtl::dense).  n: the number of particles counted.
 __device__ __forceinline__ void scan_tiles(int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
                                            int4 *__restrict__ items, int *__restrict__ n_items_out,
-                                           long long item_cap, const int kChunk)
+                                           long long item_cap, const int kChunk, const int n, const int sparse,
+                                           int *__restrict__ dense_out)
 {
-    __shared__ int wave_cnt[16], wave_itm[16];
+    __shared__ int wave_cnt[16], wave_itm[16], wave_sp[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n_waves = (int)blockDim.x >> 6;
-    int carry_cnt = 0, carry_itm = 0;
+    int carry_cnt = 0, carry_itm = 0, carry_sp = 0;
     for (int base = 0; base < n_tiles; base += 4 * (int)blockDim.x) {
         const int i0 = base + 4 * t;
-        int c[4], m[4];
+        int c[4], m[4], sp[4];      // per tile: particles, work items, particles if the tile is sparse
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             c[q] = (i0 + q < n_tiles)
                        ? __hip_atomic_load(&tile_count[i0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            sp[q] = c[q] < sparse ? c[q] : 0;
+            c[q] -= sp[q];
             m[q] = (c[q] + kChunk - 1) / kChunk;
         }
-        const int my_cnt = (c[0] + c[1]) + (c[2] + c[3]), my_itm = (m[0] + m[1]) + (m[2] + m[3]);
-        int inc_cnt = my_cnt, inc_itm = my_itm;            // inclusive scan over the wave
+        const int my_cnt = (c[0] + c[1]) + (c[2] + c[3]), my_itm = (m[0] + m[1]) + (m[2] + m[3]),
+                  my_sp = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        int inc_cnt = my_cnt, inc_itm = my_itm, inc_sp = my_sp;            // inclusive scans over the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            int a = __shfl_up(inc_cnt, off), b = __shfl_up(inc_itm, off);
-            if (lane >= off) { inc_cnt += a; inc_itm += b; }
+            int a = __shfl_up(inc_cnt, off), b = __shfl_up(inc_itm, off), d = __shfl_up(inc_sp, off);
+            if (lane >= off) { inc_cnt += a; inc_itm += b; inc_sp += d; }
         }
-        if (lane == 63) { wave_cnt[wave] = inc_cnt; wave_itm[wave] = inc_itm; }
+        if (lane == 63) { wave_cnt[wave] = inc_cnt; wave_itm[wave] = inc_itm; wave_sp[wave] = inc_sp; }
         __syncthreads();
-        int start = carry_cnt + inc_cnt - my_cnt, first_item = carry_itm + inc_itm - my_itm;
-        for (int v = 0; v < wave; v++) { start += wave_cnt[v]; first_item += wave_itm[v]; }
-        int chunk_cnt = 0, chunk_itm = 0;
-        for (int v = 0; v < n_waves; v++) { chunk_cnt += wave_cnt[v]; chunk_itm += wave_itm[v]; }
+        int start = carry_cnt + inc_cnt - my_cnt, first_item = carry_itm + inc_itm - my_itm,
+            before_sp = carry_sp + inc_sp - my_sp;
+        for (int v = 0; v < wave; v++) { start += wave_cnt[v]; first_item += wave_itm[v]; before_sp += wave_sp[v]; }
+        int chunk_cnt = 0, chunk_itm = 0, chunk_sp = 0;
+        for (int v = 0; v < n_waves; v++) { chunk_cnt += wave_cnt[v]; chunk_itm += wave_itm[v]; chunk_sp += wave_sp[v]; }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int i = i0 + q;
             if (i < n_tiles) {
-                tile_start[i] = start;
+                before_sp += sp[q];
+                tile_start[i] = sp[q] ? n - before_sp : start;      // the tail is filled from its end
                 tile_count[i] = 0;
                 // a tile that needs several items is cut into equal parts (in whole waves), not into full
                 // items and a remainder: every item pays for its arena, a small one as much as a full one
@@ -332,9 +352,10 @@ __device__ __forceinline__ void scan_tiles(int *__restrict__ tile_count, int n_t
         }
         carry_cnt += chunk_cnt;
         carry_itm += chunk_itm;
+        carry_sp += chunk_sp;
         __syncthreads();
     }
-    if (t == 0) { tile_start[n_tiles] = carry_cnt; *n_items_out = carry_itm; }
+    if (t == 0) { tile_start[n_tiles] = carry_cnt; *n_items_out = carry_itm; *dense_out = carry_cnt; }
 }
 
 // First launch: tile id per particle and its arrival rank inside the tile, then (last
@@ -343,7 +364,7 @@ __global__ void __launch_bounds__(256)
 bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict__ key, int *__restrict__ rank,
                       int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
                       int4 *__restrict__ items, int *__restrict__ n_items_out, long long item_cap,
-                      RebinCtl *ctl, int interval, int force, int divisor, int ride, int chunk)
+                      RebinCtl *ctl, int interval, int force, int divisor, int ride, int chunk, int sparse)
 {
     // tile_start, items, n_items_out: both sets; this launch fills the one that is not current.
     // ride: the re-bin, if due, rides on this step (RebinCtl::riding) instead of being completed by
@@ -388,7 +409,7 @@ bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict
         if (valid) { key[j] = k; rank[j] = base + pos; }
     }
     if (last_workgroup(&ctl->ticket)) {
-        scan_tiles(tile_count, n_tiles, tile_start, items, n_items_out, item_cap, chunk);
+        scan_tiles(tile_count, n_tiles, tile_start, items, n_items_out, item_cap, chunk, n, sparse, &ctl->dense_next);
         if (ride && threadIdx.x == 0) {      // a riding re-bin's own device time ends here
             ctl->busy_ticks += (unsigned long long)wall_clock64() - ctl->t_start;
             ctl->t_start = ~0ULL;
@@ -419,6 +440,7 @@ bin_scatter_kernel(StoreSel ss, int n, const int *__restrict__ key, const int *_
         ctl->age = 0;
         ctl->cum_drift = 0;
         ctl->binned = n;
+        ctl->dense = ctl->dense_next;
         ctl->rebins += 1;
         ctl->epoch += 1;
         ctl->busy_ticks += (unsigned long long)wall_clock64() - ctl->t_start;
@@ -429,24 +451,19 @@ bin_scatter_kernel(StoreSel ss, int n, const int *__restrict__ key, const int *_
 // A riding re-bin needs no counting launch of its own: the mass pass of the step reads every position
 // anyway, and a work item's particles have moved, if at all, into one of the 26 tiles around their own --
 // so a workgroup counts them in 27 LDS words and takes its share of the global tile counters with at
-// most 27 atomics.  ride_decide_kernel (one lane) latches the decision before the mass pass,
+// most 27 atomics.  The mass pass itself decides (every workgroup evaluates rebin_due, a pure function of
+// words nothing changes before g2p; its first workgroup latches the answer for the launches that follow),
 // ride_scan_kernel (one workgroup) turns the counts into the next item set after it.
-__global__ void ride_decide_kernel(RebinCtl *ctl, int n, int interval, int divisor)
-{
-    if (threadIdx.x != 0) return;
-    const bool due = rebin_due(ctl, n, interval, 0, divisor);
-    ctl->riding = due ? 2 : 0;      // 2: the mass pass counts the tiles
-}
-
 __global__ void __launch_bounds__(1024)
 ride_scan_kernel(RebinCtl *ctl, int *__restrict__ tile_count, int n_tiles, int *__restrict__ tile_start,
-                 int4 *__restrict__ items, int *__restrict__ n_items_out, long long item_cap, int chunk)
+                 int4 *__restrict__ items, int *__restrict__ n_items_out, long long item_cap, int chunk, int n,
+                 int sparse)
 {
     if (ctl->riding != 2) return;
     const unsigned long long t0 = wall_clock64();
     const int next_set = ctl->item_set ^ 1;
     scan_tiles(tile_count, n_tiles, tile_start + (long long)next_set * (n_tiles + 1), items + (long long)next_set * item_cap,
-               n_items_out + next_set, item_cap, chunk);
+               n_items_out + next_set, item_cap, chunk, n, sparse, &ctl->dense_next);
     if (threadIdx.x == 0) ctl->busy_ticks += (unsigned long long)wall_clock64() - t0;
 }
 
@@ -877,6 +894,9 @@ __global__ void __launch_bounds__(kTiledThreads)
 p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
     const Store st = w.store.pick();
+    // counting for a riding re-bin (uniform over the launch)
+    const bool counting = w.decide ? rebin_due(w.ctl, w.n, w.interval, 0, w.divisor) : w.ctl->riding == 2;
+    if (w.decide && blockIdx.x == 0 && threadIdx.x == 0) w.ctl->riding = counting ? 2 : 0;
     int4 item;
     if (!take_item(w, &item)) return;
     const Stragglers sg = w.sg;
@@ -886,8 +906,6 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     straggler_buf_init(sb);
     const Arena A = arena_of_tile(item.x, w.td, P);
     for (int i = threadIdx.x; i < kArenaCells; i += kTiledThreads) lds[i] = 0;
-    // counting for a riding re-bin (uniform over the launch)
-    const bool counting = w.ctl->riding == 2;
     const int tz0 = item.x % w.td.tiles_z, ty0 = (item.x / w.td.tiles_z) % w.td.tiles_y,
               tx0 = item.x / (w.td.tiles_z * w.td.tiles_y);
     if (threadIdx.x < 27) nb_count[threadIdx.x] = 0;
@@ -1391,7 +1409,10 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
             float B[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) B[k] = 0.0f;
-            if (!MODES || (M->grid_mode == 0u && !hide)) g2p_gather<true>(s, grid, abase, cellf, P, v, B);
+            // The gather always sits behind a branch the compiler cannot fold (every launch has tiles).  In
+            // one basic block with the noise field's arithmetic the chaos kernel keeps 142 VGPRs live, three
+            // waves per SIMD; in a block of its own 81, five waves: 0.620 -> 0.554 ms per launch.
+            if (MODES ? (M->grid_mode == 0u && !hide) : (w.n_tiles > 0)) g2p_gather<true>(s, grid, abase, cellf, P, v, B);
 #if FLOWMPM_G2P_PHASE_BARRIERS
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -1460,7 +1481,7 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
 __device__ __forceinline__ int straggler_total(const TiledWork &w, int *count, int *tail_begin)
 {
     *count = *w.sg.count;
-    *tail_begin = min(w.ctl->binned, w.n);
+    *tail_begin = min(w.ctl->dense, w.n);
     return *count + (w.n - *tail_begin);
 }
 
@@ -1545,8 +1566,12 @@ straggler_p2g_team_kernel(TiledWork w, FixedGrid g, Params P)
         for (int k = 0; k < 27; k++) density = density + __shfl(term, team_lane0 + k);
         if (live && c == 0) {
             const Ride ride = ride_of(w, st);
-            ride.dst.slot(kDensity)[ride.slot(j)] =
-                st.slot(kDensity)[j] * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
+            const int d = ride.slot(j);
+            ride.dst.slot(kDensity)[d] = st.slot(kDensity)[j] * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
+#if FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
+            // a particle no work item covers: nothing else carries its constant columns to the new slot
+            if (ride.on && i >= count) ride_carry_constants(st, ride.dst, j, d);
+#endif
         }
         const Eq16 e = p2g2_stress(density, C, P);
         const float dx = pick3(s.dx, gx), dy = pick3(s.dy, gy), dz = pick3(s.dz, gz);
@@ -1585,8 +1610,10 @@ straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
         w.ctl->stragglers += (unsigned long long)total;
         // bookkeeping of the step that ends here: every particle on this path counts as outside
         // (not while a re-bin rides on the step: these particles are being binned anew)
+        // (the particles of nearly empty tiles are on this path by choice: they do not count)
         if (!ride.on) {
-            if (total) atomicAdd(&w.ctl->cum_drift, total);
+            const int outside = count + (w.n - min(w.ctl->binned, w.n));
+            if (outside) atomicAdd(&w.ctl->cum_drift, outside);
             w.ctl->age += 1;
         }
     }
@@ -1645,6 +1672,7 @@ straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
         ctl->cum_drift = __hip_atomic_load(&ctl->drift_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ctl->drift_next = 0;
         ctl->binned = w.n;
+        ctl->dense = ctl->dense_next;
         ctl->rebins += 1;
         ctl->epoch += 1;
         ctl->riding = 0;
@@ -1790,6 +1818,18 @@ inline int choose_chunk(long long n)
     return std::min(kChunkMax, std::max(kChunkMin, chunk));
 }
 
+// Below how many particles a tile gets no work item (RebinCtl::dense).  FLOWMPM_SPARSE_TILE sets another
+// bound; 0 gives every occupied tile its work item.
+#ifndef FLOWMPM_SPARSE_TILE_DEFAULT
+#define FLOWMPM_SPARSE_TILE_DEFAULT 0
+#endif
+inline int choose_sparse()
+{
+    int sparse = FLOWMPM_SPARSE_TILE_DEFAULT;
+    if (const char *env = getenv("FLOWMPM_SPARSE_TILE")) sparse = atoi(env);
+    return std::min(std::max(sparse, 0), kChunkMin);
+}
+
 // Enqueues the start-of-step pair of launches (see "binning" above).  When a re-bin is due the
 // first n particles of the current store are grouped by tile into the other store, the work
 // items are rebuilt and the other store becomes current.
@@ -1809,12 +1849,12 @@ inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P
     if (force) {
         ride = 0;
         T.chunk = choose_chunk(n);      // kept until the next forced re-bin: the launch bounds rely on it
+        T.sparse = choose_sparse();
     }
     T.listed = -1;
     if (ride == 2) {
-        hipLaunchKernelGGL(ride_decide_kernel, dim3(1), dim3(64), 0, stream, T.ctl, (int)n, interval, divisor);
-        hipError_t e2 = hipGetLastError();
-        if (e2 != hipSuccess) { *msg = std::string("ride_decide launch: ") + hipGetErrorString(e2); return 1; }
+        T.ride_interval = interval;
+        T.ride_divisor = divisor;
         T.scan_after_mass = true;
         T.scan_ev_start = ev_start;
         T.scan_ev_stop = ev_stop;
@@ -1823,7 +1863,7 @@ inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P
     }
     hipExtLaunchKernelGGL(bin_count_scan_kernel, dim3(blocks), dim3(256), 0, stream, ev_start, ride ? ev_stop : nullptr,
                           0, ss, (int)n, P, tile_dims(T), T.key, T.rank, T.tile_count, T.n_tiles, T.tile_start, T.items,
-                          T.n_items, T.item_cap, T.ctl, interval, force, divisor, ride ? 1 : 0, T.chunk);
+                          T.n_items, T.item_cap, T.ctl, interval, force, divisor, ride ? 1 : 0, T.chunk, T.sparse);
     if (!ride)
         hipExtLaunchKernelGGL(bin_scatter_kernel, dim3(blocks), dim3(256), 0, stream, nullptr, ev_stop, 0, ss, (int)n,
                               T.key, T.rank, T.tile_start, T.n_tiles, T.ctl, interval, force, divisor);
@@ -1848,7 +1888,7 @@ inline TiledWork tiled_work(TiledState &T, StoreSel ss, long long n, StagePart s
                         T.straggler_list};
     if (sp.part != 1) T.stage_parity ^= 1;
     return TiledWork{ss, T.items, T.n_items, T.item_cap, T.key, T.rank, T.tile_count, T.tile_start, T.n_tiles, T.ctl, (int)n,
-                     tile_dims(T), sg, -2147483647 - 1, 2147483647, sp.part, sp.bnd_lo, sp.bnd_hi};
+                     tile_dims(T), sg, -2147483647 - 1, 2147483647, sp.part, sp.bnd_lo, sp.bnd_hi, 0, 0, 0};
 }
 
 // Upper bound of the work items any binning of n particles can produce.
@@ -1894,13 +1934,19 @@ inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedG
     TiledWork w = tiled_work(T, st, n);
     w.keep_lo = keep_lo;
     w.keep_hi = keep_hi;
+    if (T.scan_after_mass) {
+        w.decide = 1;
+        w.interval = T.ride_interval;
+        w.divisor = T.ride_divisor;
+    }
     hipExtLaunchKernelGGL(p2g_mass_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, ev_start,
                           ev_stop, 0, w, g, P);
     hipLaunchKernelGGL(straggler_p2g_team_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
     if (T.scan_after_mass) {
         T.scan_after_mass = false;
         hipExtLaunchKernelGGL(ride_scan_kernel, dim3(1), dim3(1024), 0, stream, T.scan_ev_start, T.scan_ev_stop, 0, T.ctl,
-                              T.tile_count, T.n_tiles, T.tile_start, T.items, T.n_items, T.item_cap, T.chunk);
+                              T.tile_count, T.n_tiles, T.tile_start, T.items, T.n_items, T.item_cap, T.chunk, (int)n,
+                              T.sparse);
     }
     return 0;
 }
