@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 mkdir -p build_variants
 build_one() {
     name=$1; flags=$2
-    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Wno-unused-function \
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -mllvm -disable-vector-combine -fPIC -shared -Wno-unused-function \
         -Rpass-analysis=kernel-resource-usage $flags -o build_variants/$name.so flow_amd/csrc/flowmpm.hip > build_variants/$name.log 2>&1
     if grep -q "error" build_variants/$name.log; then echo "$name: BUILD FAILED"; grep error build_variants/$name.log | head -3; return; fi
     python3 - "$name" <<'PY'
