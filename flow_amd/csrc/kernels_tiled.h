@@ -717,6 +717,10 @@ __device__ __forceinline__ bool stencil_in_arena(const Stencil &s, const Arena &
 {
     const int bx = s.cx - A.ox, by = s.cy - A.oy, bz = s.cz - A.oz;   // arena coords of the stencil base
     *abase = arena_index(bx, by, bz);
+#if FLOWMPM_ABLATE & 64      // timing experiment (wrong results): every 32 lanes hold 32 different banks
+    *abase = (*abase & ~31) | (int)(threadIdx.x & 31);
+    if (*abase > kArenaCells - 1 - arena_index(2, 2, 2)) *abase -= 32;
+#endif
     return (unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
            (unsigned)bz <= (unsigned)(kAZ - 3);
 }
