@@ -709,13 +709,17 @@ def test_per_frame_reads_allocate_nothing_after_the_first():
     h.close()
 
 
+@pytest.mark.parametrize("sparse", ["0", "120"], ids=["every_tile_an_item", "sparse_tiles_in_the_tail"])
 @pytest.mark.parametrize("form", ["0", "1", "2"], ids=["standalone", "own_count", "mass_pass_count"])
-def test_every_form_of_the_rebin_gives_the_same_bits(oracle_binding, monkeypatch, form):
+def test_every_form_of_the_rebin_gives_the_same_bits(oracle_binding, monkeypatch, form, sparse):
     """The re-bin of flowmpm_step exists in three forms (FLOWMPM_RIDE_REBINS): standalone, riding on the
     step with a counting launch of its own, riding with the count in the mass pass.  Each must leave the
     oracle's bits -- with a re-bin in every step, with the device deciding, with stages run one by one and
-    downloads in between, with the live count changed and with particles replaced while a binning exists."""
+    downloads in between, with the live count changed and with particles replaced while a binning exists.
+    FLOWMPM_SPARSE_TILE = 120 (the scene holds about 150 particles per tile) also keeps the particles of
+    the emptier tiles out of the work items, at the end of the store, in every one of those situations."""
     monkeypatch.setenv("FLOWMPM_RIDE_REBINS", form)
+    monkeypatch.setenv("FLOWMPM_SPARSE_TILE", sparse)
     ob = oracle_binding
     grid, n = (40, 24, 32), 9000
     rec = moving_particles(n, grid, seed=61, vel=2.5)
@@ -756,4 +760,6 @@ def test_every_form_of_the_rebin_gives_the_same_bits(oracle_binding, monkeypatch
         t = h.timings()["rebin"]
         if interval == 1:
             assert t["performed"] >= 15, t
+        if sparse != "0":
+            assert t["stragglers"] > 16 * 100, t      # the tail takes the follow-up kernels' path in every step
         h.close()
