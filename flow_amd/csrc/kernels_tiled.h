@@ -56,9 +56,6 @@ constexpr int kChunkMax = 16 * kTiledThreads, kChunkMin = kTiledThreads;
 #ifndef FLOWMPM_G2P_WAVES
 #define FLOWMPM_G2P_WAVES 1
 #endif
-#ifndef FLOWMPM_G2P_B128
-#define FLOWMPM_G2P_B128 0   // measured: 16-byte reads cost 8 VGPRs and 2% of g2p
-#endif
 // Timing experiments only (WRONG results; tools/ablate.sh): bit 0 g2p's gather without its LDS reads,
 // bit 1 g2p without the noise field, bit 2 g2p without its stores, bit 3 the momentum pass without its LDS
 // atomics, bit 4 the momentum pass without the mass reads of its density sum.
@@ -73,24 +70,6 @@ constexpr int kChunkMax = 16 * kTiledThreads, kChunkMin = kTiledThreads;
 #endif
 #ifndef FLOWMPM_EXP_NO_SETUP
 #define FLOWMPM_EXP_NO_SETUP 0
-#endif
-#ifndef FLOWMPM_G2P_READ_ALL
-#define FLOWMPM_G2P_READ_ALL 0
-#endif
-#ifndef FLOWMPM_G2P_PHASE_BARRIERS
-#define FLOWMPM_G2P_PHASE_BARRIERS 0
-#endif
-#ifndef FLOWMPM_SLAB_FENCE
-#define FLOWMPM_SLAB_FENCE 1
-#endif
-// Software prefetch of the next particle's fields: neutral to slightly negative in g2p since its
-// sums became packed (0.633 vs 0.625 ms), negative in the momentum pass (15 more VGPRs cost a
-// wave per SIMD).
-#ifndef FLOWMPM_PREFETCH_G2P
-#define FLOWMPM_PREFETCH_G2P 0
-#endif
-#ifndef FLOWMPM_PREFETCH_P2G
-#define FLOWMPM_PREFETCH_P2G 0
 #endif
 
 // Diagnostic build only (-DFLOWMPM_STAMPS=1, tools/clock_stamps.py): every workgroup of the momentum
@@ -606,23 +585,15 @@ __device__ __forceinline__ void flush_arena(const int *lds, const Arena &A, cons
     }
 }
 
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each with
-// its own L2.  Work items are ordered by tile, and neighbouring tiles share arena cells, so
-// every XCD gets a contiguous run of items: the shared cells then hit in that XCD's L2.
-// Placement only affects speed.  Returns -1 for the surplus blocks of the launch bound.
-#ifndef FLOWMPM_XCD_REMAP
-#define FLOWMPM_XCD_REMAP 0   // measured 3% slower on the ellipsoid scene: contiguous item runs per XCD are unbalanced
-#endif
+// The work item of a workgroup, or -1 for the surplus blocks of the launch bound.  Workgroups are dealt
+// round-robin over the 8 XCDs, each with its own L2; handing every XCD one contiguous run of items
+// (neighbouring tiles share arena cells) measured 3 % slower on the ellipsoid scene, because such runs
+// hold unequal work, so block b simply takes item b.
 __device__ __forceinline__ int item_for_block(int n_items)
 {
     const int b = blockIdx.x;
     if (b >= n_items) return -1;
-#if FLOWMPM_XCD_REMAP
-    const int q = n_items >> 3, r = n_items & 7, xcd = b & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-#else
     return b;
-#endif
 }
 
 // The work item of this workgroup, clipped to the live particles; false when there is none.
@@ -1197,13 +1168,6 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 #else
     while (j < item.z) {
         const int jn = j + kTiledThreads;
-#if FLOWMPM_PREFETCH_P2G
-        float nx[15];
-        if (jn < item.z) {
-#pragma unroll
-            for (int k = 0; k < 15; k++) nx[k] = st.slot(kPosX + k)[jn];
-        }
-#endif
         Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
         int abase;
         const int d = ride.slot(j);
@@ -1215,15 +1179,10 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
                                         dens_out + d, lds, mass_f, abase, g, P);
         else
             add_straggler(sg, sb, j);
-#if FLOWMPM_PREFETCH_P2G
-#pragma unroll
-        for (int k = 0; k < 15; k++) in[k] = nx[k];
-#else
         if (jn < item.z) {
 #pragma unroll
             for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[jn];
         }
-#endif
         j = jn;
     }
 #endif
@@ -1253,20 +1212,6 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
     float B8 = B[8];
     Float2v vxy = {v.x, v.y};
     float vz = v.z;
-#if FLOWMPM_G2P_READ_ALL
-    // All 27 arena reads are issued before the first use, so that the round trip to the LDS is paid once
-    // per particle and not once per row of the stencil (left to itself the compiler issues three reads
-    // and waits for them, nine times over).
-    float fx[27], fy[27], fz[27];
-    if (INSIDE) {
-#pragma unroll
-        for (int c = 0; c < 27; c++) {
-            const float4 f = grid[abase + arena_index(c / 9, (c / 3) % 3, c % 3)];
-            fx[c] = f.x; fy[c] = f.y; fz[c] = f.z;
-        }
-        asm volatile("" ::: "memory");
-    }
-#endif
 #pragma unroll
     for (int gx = 0; gx < 3; gx++)
 #pragma unroll
@@ -1280,17 +1225,10 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                 const float weight = gz == 0 ? w01.x : gz == 1 ? w01.y : w2;
                 float4 f;
                 if (INSIDE) {
-#if FLOWMPM_G2P_READ_ALL
-                    f = make_float4(fx[(gx * 3 + gy) * 3 + gz], fy[(gx * 3 + gy) * 3 + gz], fz[(gx * 3 + gy) * 3 + gz], 0.0f);
-#elif FLOWMPM_ABLATE & 1
+#if FLOWMPM_ABLATE & 1
                     f = make_float4(s.wx[gx], s.wy[gy], s.wz[gz], 0.0f);
 #else
                     f = grid[abase + arena_index(gx, gy, gz)];
-#endif
-#if FLOWMPM_G2P_B128
-                    // keep the read 16 bytes wide: ds_read_b128 takes half the LDS cycles of the
-                    // ds_read_b96 the compiler picks when only xyz is used
-                    asm volatile("" :: "v"(f.w));
 #endif
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
@@ -1315,13 +1253,8 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                 vxy = vxy + wvxy;
                 vz = vz + wvz;
             }
-#if FLOWMPM_G2P_READ_ALL
-#elif FLOWMPM_SLAB_FENCE == 1
             // keep the compiler from hoisting all 27 arena reads (108 VGPRs) to the top
             if (INSIDE) asm volatile("" ::: "memory");
-#elif FLOWMPM_SLAB_FENCE == 2
-            if (INSIDE) __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     B[0] = B01.x; B[1] = B01.y; B[3] = B34.x; B[4] = B34.y; B[6] = B67.x; B[7] = B67.y;
     B[2] = B25.x; B[5] = B25.y; B[8] = B8;
@@ -1367,9 +1300,6 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
     // Software pipeline: the next particle's loads are issued before this particle's 18 stores
     // (the memory counter retires in order, so a load issued after them would wait for them).
     G2PIn in;
-#if FLOWMPM_PREFETCH_G2P
-    G2PIn nx;
-#endif
     int j = item.y + threadIdx.x;
     auto load = [&](G2PIn &r, int q) {
         r.px = st.slot(kPosX)[q]; r.py = st.slot(kPosY)[q]; r.pz = st.slot(kPosZ)[q];
@@ -1390,9 +1320,6 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
     stamp.begin();
     while (j < item.z) {
         const int jn = j + kTiledThreads;
-#if FLOWMPM_PREFETCH_G2P
-        if (jn < item.z) load(nx, jn);
-#endif
         Stencil s = make_stencil(in.px, in.py, in.pz);
         int abase;
         if (stencil_in_arena(s, A, &abase)) {
@@ -1407,9 +1334,6 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
             }
             else
                 v = g2p_pre_forces(in.px, in.py, in.pz, P);
-#if FLOWMPM_G2P_PHASE_BARRIERS
-            __builtin_amdgcn_sched_barrier(0);     // let the noise temporaries die before the gather
-#endif
             float B[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) B[k] = 0.0f;
@@ -1417,9 +1341,6 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
             // one basic block with the noise field's arithmetic the chaos kernel keeps 142 VGPRs live, three
             // waves per SIMD; in a block of its own 81, five waves: 0.620 -> 0.554 ms per launch.
             if (MODES ? (M->grid_mode == 0u && !hide) : (w.n_tiles > 0)) g2p_gather<true>(s, grid, abase, cellf, P, v, B);
-#if FLOWMPM_G2P_PHASE_BARRIERS
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             G2POut o = MODES ? g2p_finish_modes(in, v, B, index, hide, P, M) : g2p_finish(in, v, B, P);
             // While a re-bin rides on this step the record goes to its slot of the other store, and the
             // columns no kernel of the step writes travel with it (the density went there with the
@@ -1458,11 +1379,7 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
         } else if (!LISTED) {
             add_straggler_direct(sg, j);
         }
-#if FLOWMPM_PREFETCH_G2P
-        in = nx;
-#else
         if (jn < item.z) load(in, jn);
-#endif
         j = jn;
     }
     stamp.end(1);
