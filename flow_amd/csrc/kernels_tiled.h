@@ -48,6 +48,7 @@ constexpr int kArenaPad = kArenaCells + 8;     // component stride in LDS (dword
 #endif
 constexpr int kTiledThreads = FLOWMPM_TILED_THREADS;
 constexpr int kChunkMax = 16 * kTiledThreads, kChunkMin = kTiledThreads;
+constexpr int kLargeItem = 1024;     // particles; see scan_tiles
 // Minimum waves per SIMD the register allocator must leave room for (second argument of
 // __launch_bounds__) in the two register-heavy kernels; measured, not guessed.
 #ifndef FLOWMPM_P2G_WAVES
@@ -175,7 +176,7 @@ struct TiledState {
     // while the kernels of the step it rides on still read the current one.
     int *tile_start = nullptr;   // 2 x [n_tiles + 1]
     int4 *items = nullptr;       // 2 x item_cap work items {tile, begin, end, 0}
-    int *n_items = nullptr;      // 2 device scalars
+    int *n_items = nullptr;      // 2 x 2 device scalars: the two sets' items, then their large items
     int *straggler_counts = nullptr;   // two device scalars used by alternate stages
     int *straggler_list = nullptr;
     int chunk = kChunkMax;       // particles per work item of the current binning (choose_chunk)
@@ -274,6 +275,11 @@ __device__ __forceinline__ bool last_workgroup(int *ticket)
 // for the next re-bin.  The counts were produced by device-scope atomics of other workgroups
 // of the same launch, hence the device-scope loads.
 //
+// The list is ordered for the dispatcher, which hands out workgroups in block order: items of at least
+// kLargeItem particles first, the small ones last, so that the launch ends on short workgroups (in tile
+// order its last round of workgroups held full items: 550 instead of 537 us in a replay of the momentum
+// pass's item durations over 1,280 slots).
+//
 // Tiles with fewer than `sparse` particles get no work item: their particles are placed at the end of
 // the store, [n - their number, n), the others from slot 0 on, and *dense_out receives the first slot of
 // that tail (RebinCtl::dense).  n: the number of particles counted.
@@ -282,35 +288,47 @@ __device__ __forceinline__ void scan_tiles(int *__restrict__ tile_count, int n_t
                                            long long item_cap, const int kChunk, const int n, const int sparse,
                                            int *__restrict__ dense_out)
 {
-    __shared__ int wave_cnt[16], wave_itm[16], wave_sp[16];
+    __shared__ int wave_cnt[16], wave_itm[16], wave_sml[16], wave_sp[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n_waves = (int)blockDim.x >> 6;
-    int carry_cnt = 0, carry_itm = 0, carry_sp = 0;
+    int carry_cnt = 0, carry_itm = 0, carry_sml = 0, carry_sp = 0;
     for (int base = 0; base < n_tiles; base += 4 * (int)blockDim.x) {
         const int i0 = base + 4 * t;
-        int c[4], m[4], sp[4];      // per tile: particles, work items, particles if the tile is sparse
+        // per tile: particles, large work items, small work items, particles if the tile is sparse
+        int c[4], m[4], ms[4], sp[4], per[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             c[q] = (i0 + q < n_tiles)
                        ? __hip_atomic_load(&tile_count[i0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             sp[q] = c[q] < sparse ? c[q] : 0;
             c[q] -= sp[q];
-            m[q] = (c[q] + kChunk - 1) / kChunk;
+            const int parts = (c[q] + kChunk - 1) / kChunk;
+            // a tile that needs several items is cut into equal parts (in whole waves), not into full
+            // items and a remainder: every item pays for its arena, a small one as much as a full one
+            per[q] = parts > 0 ? ((c[q] + parts - 1) / parts + 63) / 64 * 64 : 0;
+            const bool large = per[q] >= kLargeItem;
+            m[q] = large ? parts : 0;
+            ms[q] = large ? 0 : parts;
         }
         const int my_cnt = (c[0] + c[1]) + (c[2] + c[3]), my_itm = (m[0] + m[1]) + (m[2] + m[3]),
-                  my_sp = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-        int inc_cnt = my_cnt, inc_itm = my_itm, inc_sp = my_sp;            // inclusive scans over the wave
+                  my_sml = (ms[0] + ms[1]) + (ms[2] + ms[3]), my_sp = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        int inc_cnt = my_cnt, inc_itm = my_itm, inc_sml = my_sml, inc_sp = my_sp;      // inclusive scans over the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            int a = __shfl_up(inc_cnt, off), b = __shfl_up(inc_itm, off), d = __shfl_up(inc_sp, off);
-            if (lane >= off) { inc_cnt += a; inc_itm += b; inc_sp += d; }
+            int a = __shfl_up(inc_cnt, off), b = __shfl_up(inc_itm, off), d = __shfl_up(inc_sp, off),
+                e = __shfl_up(inc_sml, off);
+            if (lane >= off) { inc_cnt += a; inc_itm += b; inc_sp += d; inc_sml += e; }
         }
-        if (lane == 63) { wave_cnt[wave] = inc_cnt; wave_itm[wave] = inc_itm; wave_sp[wave] = inc_sp; }
+        if (lane == 63) { wave_cnt[wave] = inc_cnt; wave_itm[wave] = inc_itm; wave_sml[wave] = inc_sml; wave_sp[wave] = inc_sp; }
         __syncthreads();
         int start = carry_cnt + inc_cnt - my_cnt, first_item = carry_itm + inc_itm - my_itm,
-            before_sp = carry_sp + inc_sp - my_sp;
-        for (int v = 0; v < wave; v++) { start += wave_cnt[v]; first_item += wave_itm[v]; before_sp += wave_sp[v]; }
-        int chunk_cnt = 0, chunk_itm = 0, chunk_sp = 0;
-        for (int v = 0; v < n_waves; v++) { chunk_cnt += wave_cnt[v]; chunk_itm += wave_itm[v]; chunk_sp += wave_sp[v]; }
+            first_small = carry_sml + inc_sml - my_sml, before_sp = carry_sp + inc_sp - my_sp;
+        for (int v = 0; v < wave; v++) {
+            start += wave_cnt[v]; first_item += wave_itm[v]; first_small += wave_sml[v]; before_sp += wave_sp[v];
+        }
+        int chunk_cnt = 0, chunk_itm = 0, chunk_sml = 0, chunk_sp = 0;
+        for (int v = 0; v < n_waves; v++) {
+            chunk_cnt += wave_cnt[v]; chunk_itm += wave_itm[v]; chunk_sml += wave_sml[v]; chunk_sp += wave_sp[v];
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int i = i0 + q;
@@ -318,23 +336,30 @@ __device__ __forceinline__ void scan_tiles(int *__restrict__ tile_count, int n_t
                 before_sp += sp[q];
                 tile_start[i] = sp[q] ? n - before_sp : start;      // the tail is filled from its end
                 tile_count[i] = 0;
-                // a tile that needs several items is cut into equal parts (in whole waves), not into full
-                // items and a remainder: every item pays for its arena, a small one as much as a full one
-                const int per = m[q] > 0 ? ((c[q] + m[q] - 1) / m[q] + 63) / 64 * 64 : 0;
-                for (int k = 0; k < m[q]; k++)
-                    if (first_item + k < item_cap)
-                        items[first_item + k] =
-                            make_int4(i, min(start + k * per, start + c[q]), min(start + (k + 1) * per, start + c[q]), 0);
+                // large items from the front of the list, small ones from its back (take_item)
+                for (int k = 0; k < m[q] + ms[q]; k++) {
+                    const long long at = m[q] ? first_item + k : item_cap - 1 - (first_small + k);
+                    if (at >= 0 && at < item_cap)
+                        items[at] = make_int4(i, min(start + k * per[q], start + c[q]),
+                                              min(start + (k + 1) * per[q], start + c[q]), 0);
+                }
                 start += c[q];
                 first_item += m[q];
+                first_small += ms[q];
             }
         }
         carry_cnt += chunk_cnt;
         carry_itm += chunk_itm;
+        carry_sml += chunk_sml;
         carry_sp += chunk_sp;
         __syncthreads();
     }
-    if (t == 0) { tile_start[n_tiles] = carry_cnt; *n_items_out = carry_itm; *dense_out = carry_cnt; }
+    if (t == 0) {
+        tile_start[n_tiles] = carry_cnt;
+        n_items_out[0] = (int)min((long long)carry_itm + carry_sml, item_cap);
+        n_items_out[2] = carry_itm;      // the large ones (the two sets' totals sit in words 0 and 1, these in 2 and 3)
+        *dense_out = carry_cnt;
+    }
 }
 
 // First launch: tile id per particle and its arrival rank inside the tile, then (last
@@ -602,7 +627,8 @@ __device__ __forceinline__ bool take_item(const TiledWork &w, int4 *item)
     const int set = w.ctl->item_set;
     const int id = item_for_block(w.n_items[set]);
     if (id < 0) return false;
-    *item = w.items[(long long)set * w.item_cap + id];
+    const int large = w.n_items[2 + set];      // these from the front of the list, the small ones from its back
+    *item = w.items[(long long)set * w.item_cap + (id < large ? id : w.item_cap - 1 - (id - large))];
     item->z = min(item->z, w.n);
     if (w.part != 0) {
         const int tx = item->x / (w.td.tiles_y * w.td.tiles_z);
@@ -1689,8 +1715,8 @@ inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStr
     if (chk(e = hipMemsetAsync(T.tile_count, 0, (size_t)T.n_tiles * sizeof(int), stream), "memset tile_count")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.tile_start), 2 * (size_t)(T.n_tiles + 1) * sizeof(int)), "hipMalloc tile_start")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.items), 2 * (size_t)T.item_cap * sizeof(int4)), "hipMalloc items")) return 1;
-    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.n_items), 2 * sizeof(int)), "hipMalloc n_items")) return 1;
-    if (chk(e = hipMemsetAsync(T.n_items, 0, 2 * sizeof(int), stream), "memset n_items")) return 1;
+    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.n_items), 4 * sizeof(int)), "hipMalloc n_items")) return 1;
+    if (chk(e = hipMemsetAsync(T.n_items, 0, 4 * sizeof(int), stream), "memset n_items")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.straggler_counts), 256), "hipMalloc straggler counts")) return 1;
     if (chk(e = hipMemsetAsync(T.straggler_counts, 0, 256, stream), "memset straggler counts")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.straggler_list), (size_t)capacity * sizeof(int)), "hipMalloc straggler list")) return 1;
