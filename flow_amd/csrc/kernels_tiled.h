@@ -17,6 +17,7 @@
 // costs speed, never correctness.
 #pragma once
 
+#include <cstddef>
 #include <string>
 
 #include "kernels_migrate.h"
@@ -135,8 +136,20 @@ struct Stragglers {
 // Re-binning control words, on the device.  The decision to re-bin is taken there, from the
 // number of particles that sit outside their bin's arena, so that the host can enqueue any
 // number of steps ahead and a burst of fast particles still triggers a re-bin at once.
-struct RebinCtl {
+struct alignas(32) RebinCtl {
+    // The head: what every workgroup of a tiled kernel needs before it can start, laid out so that it
+    // arrives with ONE 32-byte scalar load (CtlHead below; read one after the other -- the current store,
+    // then the item set, then its item count -- these words were three dependent round trips).
     int cur;         // which of the two stores is current (StoreSel::cur points here)
+    int item_set;    // which of the two item sets (work items, tile_start) is current
+    // A re-bin that "rides" on a step: the step's first launch decides it, counts the tiles and builds
+    // the next item set; the momentum pass and g2p of the same step then store what they store anyway
+    // into the particle's slot of the OTHER store, and the last workgroup of the step commits.
+    int riding;      // latched by the step's binning launch: this step's stores go to the other store
+                     // (1: that launch counted the tiles, 2: the step's mass pass counts them)
+    int head_pad;
+    int n_items[4];  // work items of the two sets, then the large ones among them (scan_tiles)
+    // ---- end of the head ----
     int ticket;      // workgroups of the running binning kernel that have finished
     int age;         // g2p stages since the last re-bin
     int cum_drift;   // sum over those stages of the particles left outside their arena
@@ -154,14 +167,16 @@ struct RebinCtl {
     unsigned long long t_start;      // ~0 when no re-bin is in flight
     int epoch;       // re-bins performed since the store was created (never cleared): slot indices
                      // taken under one epoch are stale under the next
-    // A re-bin that "rides" on a step: the step's first launch decides it, counts the tiles and builds
-    // the next item set; the momentum pass and g2p of the same step then store what they store anyway
-    // into the particle's slot of the OTHER store, and the last workgroup of the step commits.
-    int riding;      // latched by the step's binning launch: this step's stores go to the other store
-                     // (1: that launch counted the tiles, 2: the step's mass pass counts them)
     int drift_next;  // particles g2p leaves outside the arena of their NEW tile during a riding re-bin
-    int item_set;    // which of the two item sets (work items, tile_start) is current
 };
+
+// The first 32 bytes of RebinCtl as one value.
+struct alignas(32) CtlHead {
+    int cur, item_set, riding, head_pad;
+    int n_items[4];
+};
+static_assert(offsetof(RebinCtl, n_items) == offsetof(CtlHead, n_items) && offsetof(RebinCtl, riding) == offsetof(CtlHead, riding) &&
+              offsetof(RebinCtl, item_set) == offsetof(CtlHead, item_set) && offsetof(RebinCtl, cur) == 0, "CtlHead mirrors RebinCtl");
 
 struct TiledState {
     bool valid = false;          // false: the next decision is forced to "re-bin"
@@ -176,7 +191,7 @@ struct TiledState {
     // while the kernels of the step it rides on still read the current one.
     int *tile_start = nullptr;   // 2 x [n_tiles + 1]
     int4 *items = nullptr;       // 2 x item_cap work items {tile, begin, end, 0}
-    int *n_items = nullptr;      // 2 x 2 device scalars: the two sets' items, then their large items
+    int *n_items = nullptr;      // RebinCtl::n_items of `ctl` (no allocation of its own)
     int *straggler_counts = nullptr;   // two device scalars used by alternate stages
     int *straggler_list = nullptr;
     int chunk = kChunkMax;       // particles per work item of the current binning (choose_chunk)
@@ -621,13 +636,17 @@ __device__ __forceinline__ int item_for_block(int n_items)
     return b;
 }
 
+// The head of the control words, by one scalar load.
+__device__ __forceinline__ CtlHead load_head(const RebinCtl *ctl) { return *reinterpret_cast<const CtlHead *>(ctl); }
+
 // The work item of this workgroup, clipped to the live particles; false when there is none.
-__device__ __forceinline__ bool take_item(const TiledWork &w, int4 *item)
+__device__ __forceinline__ bool take_item(const TiledWork &w, const CtlHead &h, int4 *item)
 {
-    const int set = w.ctl->item_set;
-    const int id = item_for_block(w.n_items[set]);
+    const int set = h.item_set;
+    // (selects, not h.n_items[set]: a dynamically indexed copy of the head would live in scratch memory)
+    const int id = item_for_block(set ? h.n_items[1] : h.n_items[0]);
     if (id < 0) return false;
-    const int large = w.n_items[2 + set];      // these from the front of the list, the small ones from its back
+    const int large = set ? h.n_items[3] : h.n_items[2];      // these from the front of the list, the small ones from its back
     *item = w.items[(long long)set * w.item_cap + (id < large ? id : w.item_cap - 1 - (id - large))];
     item->z = min(item->z, w.n);
     if (w.part != 0) {
@@ -637,6 +656,7 @@ __device__ __forceinline__ bool take_item(const TiledWork &w, int4 *item)
     }
     return item->y < item->z;
 }
+__device__ __forceinline__ bool take_item(const TiledWork &w, int4 *item) { return take_item(w, load_head(w.ctl), item); }
 
 // Where a kernel stores a particle's record while a re-bin rides on the step: slot
 // tile_start[key] + rank of the other store (key, rank and the next set's tile_start were written by
@@ -658,12 +678,13 @@ __device__ __forceinline__ void ride_carry_constants(const Store &src, const Sto
     dst.ids()[d] = src.ids()[j];
 }
 
-__device__ __forceinline__ Ride ride_of(const TiledWork &w, const Store &cur)
+__device__ __forceinline__ Ride ride_of(const TiledWork &w, const CtlHead &h, const Store &cur)
 {
-    const bool on = w.ctl->riding != 0;
-    return Ride{on, on ? w.store.other() : cur, w.key, w.rank,
-                w.tile_start + (long long)(w.ctl->item_set ^ 1) * (w.n_tiles + 1)};
+    const bool on = h.riding != 0;
+    const Store other{h.cur ? w.store.base[0] : w.store.base[1], w.store.capacity};
+    return Ride{on, on ? other : cur, w.key, w.rank, w.tile_start + (long long)(h.item_set ^ 1) * (w.n_tiles + 1)};
 }
+__device__ __forceinline__ Ride ride_of(const TiledWork &w, const Store &cur) { return ride_of(w, load_head(w.ctl), cur); }
 
 // ---- p2g1 (SIM:295-333) ------------------------------------------------------------
 
@@ -894,12 +915,13 @@ __device__ __forceinline__ void p2g_mass_particle(const Stencil &s, int *lds, in
 __global__ void __launch_bounds__(kTiledThreads)
 p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
-    const Store st = w.store.pick();
+    const CtlHead head = load_head(w.ctl);
+    const Store st{head.cur ? w.store.base[1] : w.store.base[0], w.store.capacity};
     // counting for a riding re-bin (uniform over the launch)
-    const bool counting = w.decide ? rebin_due(w.ctl, w.n, w.interval, 0, w.divisor) : w.ctl->riding == 2;
+    const bool counting = w.decide ? rebin_due(w.ctl, w.n, w.interval, 0, w.divisor) : head.riding == 2;
     if (w.decide && blockIdx.x == 0 && threadIdx.x == 0) w.ctl->riding = counting ? 2 : 0;
     int4 item;
-    if (!take_item(w, &item)) return;
+    if (!take_item(w, head, &item)) return;
     const Stragglers sg = w.sg;
     __shared__ int lds[kArenaCells];
     __shared__ StragglerBuf sb;
@@ -1134,9 +1156,10 @@ __device__ __forceinline__ void p2g_momentum_particle_reduced(const Stencil &s, 
 __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_P2G_WAVES)
 p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
-    const Store st = w.store.pick();
+    const CtlHead head = load_head(w.ctl);
+    const Store st{head.cur ? w.store.base[1] : w.store.base[0], w.store.capacity};
     int4 item;
-    if (!take_item(w, &item)) return;
+    if (!take_item(w, head, &item)) return;
     const Stragglers sg = w.sg;
     ClockStamp stamp;
     stamp.entered();
@@ -1158,7 +1181,7 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     }
     __syncthreads();
     const Column<float> dens = st.slot(kDensity);
-    const Ride ride = ride_of(w, st);
+    const Ride ride = ride_of(w, head, st);
     const Column<float> dens_out = ride.dst.slot(kDensity);
 #if !FLOWMPM_WAVE_REDUCE
     float in[15];
@@ -1295,9 +1318,10 @@ __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_G2P_WAVES)
 g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
                  const ModeParams *__restrict__ M)
 {
-    const Store st = w.store.pick();
+    const CtlHead head = load_head(w.ctl);
+    const Store st{head.cur ? w.store.base[1] : w.store.base[0], w.store.capacity};
     int4 item;
-    if (!take_item(w, &item)) return;
+    if (!take_item(w, head, &item)) return;
     const Stragglers sg = w.sg;
     ClockStamp stamp;
     stamp.entered();
@@ -1334,7 +1358,7 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
         r.dirx = st.slot(kDirX)[q]; r.diry = st.slot(kDirY)[q]; r.dirz = st.slot(kDirZ)[q];
     };
     int drifted = 0;    // particles this thread leaves outside the arena: stragglers of the next step
-    const Ride ride = ride_of(w, st);
+    const Ride ride = ride_of(w, head, st);
     const Store out = ride.dst;
     load(in, min(j, item.z - 1));          // unconditional, for the same reason
 #pragma unroll
@@ -1715,8 +1739,6 @@ inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStr
     if (chk(e = hipMemsetAsync(T.tile_count, 0, (size_t)T.n_tiles * sizeof(int), stream), "memset tile_count")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.tile_start), 2 * (size_t)(T.n_tiles + 1) * sizeof(int)), "hipMalloc tile_start")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.items), 2 * (size_t)T.item_cap * sizeof(int4)), "hipMalloc items")) return 1;
-    if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.n_items), 4 * sizeof(int)), "hipMalloc n_items")) return 1;
-    if (chk(e = hipMemsetAsync(T.n_items, 0, 4 * sizeof(int), stream), "memset n_items")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.straggler_counts), 256), "hipMalloc straggler counts")) return 1;
     if (chk(e = hipMemsetAsync(T.straggler_counts, 0, 256, stream), "memset straggler counts")) return 1;
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.straggler_list), (size_t)capacity * sizeof(int)), "hipMalloc straggler list")) return 1;
@@ -1724,6 +1746,7 @@ inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStr
     if (chk(e = hipMalloc(reinterpret_cast<void **>(&T.ctl), sizeof(RebinCtl)), "hipMalloc rebin control")) return 1;
     if (chk(e = hipMemsetAsync(T.ctl, 0, sizeof(RebinCtl), stream), "memset rebin control")) return 1;
     if (chk(e = hipMemsetAsync(&T.ctl->t_start, 0xFF, sizeof(unsigned long long), stream), "memset rebin clock")) return 1;
+    T.n_items = reinterpret_cast<int *>(reinterpret_cast<char *>(T.ctl) + offsetof(RebinCtl, n_items));
     T.valid = false;
     T.checked = false;
     return 0;
@@ -1736,7 +1759,6 @@ inline void tiled_free(TiledState &T)
     if (T.tile_count) (void)hipFree(T.tile_count);
     if (T.tile_start) (void)hipFree(T.tile_start);
     if (T.items) (void)hipFree(T.items);
-    if (T.n_items) (void)hipFree(T.n_items);
     if (T.straggler_counts) (void)hipFree(T.straggler_counts);
     if (T.straggler_list) (void)hipFree(T.straggler_list);
     if (T.ctl) (void)hipFree(T.ctl);
