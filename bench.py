@@ -370,18 +370,39 @@ def run_single(args):
     return line
 
 
+class _SingleRank:
+    """What run_distributed asks of torch.distributed, for a world of one rank (`--one-slab`)."""
+
+    class ReduceOp:
+        MAX = "max"
+
+    def is_initialized(self):
+        return False
+
+    def barrier(self):
+        pass
+
+    def all_reduce(self, tensor, op=None):
+        pass
+
+    def all_gather(self, out_list, tensor):
+        out_list[0].copy_(tensor)
+
+    def destroy_process_group(self):
+        pass
+
+
 def run_distributed(args):
     import torch
     import torch.distributed as dist
     from flow_amd import _lib
     from flow_amd.slab import SlabSimulation, balanced_plane_starts
 
-    if args.one_slab and "WORLD_SIZE" not in os.environ:
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
-        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        args.dist_backend = "gloo"          # nothing travels: the process group only answers world size 1
+    single = args.one_slab and "WORLD_SIZE" not in os.environ
+    if single:
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        dist = _SingleRank()                # nothing travels: no process group is needed
+        args.dist_backend = "none"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     n_devices = max(torch.cuda.device_count(), 1)
     local_rank = int(os.environ.get("LOCAL_RANK", rank)) % n_devices
@@ -396,6 +417,8 @@ def run_distributed(args):
     if args.dist_backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         comm_dev = torch.device("cuda", local_rank)
+    elif single:
+        comm_dev = torch.device("cpu")
     else:
         dist.init_process_group("gloo")
         comm_dev = torch.device("cpu")

@@ -180,3 +180,20 @@ def test_the_plain_two_gpu_command():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and set(LINE_KEYS) <= set(d)
     assert sum(d["config"]["resident_per_rank_end"]) == 2 << 18
+
+
+@pytest.mark.gpu
+def test_the_one_slab_line():
+    """`--one-slab`: one rank's share of the weak-scaling problem through the multi-GPU code path, no
+    process group, exactly one line on stdout."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--one-slab", "--particles-log2", "18",
+                        "--slab-yz", "64", "--slab-x-per-gpu", "32", "--steps", "6", "--warmup", "2",
+                        "--timing-stride", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and set(LINE_KEYS) <= set(d)
+    assert d["config"]["grid"] == [32, 64, 64] and d["config"]["resident_per_rank_end"] == [1 << 18]
+    assert d["config"]["parallelism"] == "slab1" and d["config"]["transport"] == "none"
