@@ -60,7 +60,9 @@ constexpr int kLargeItem = 1024;     // particles; see scan_tiles
 #endif
 // Timing experiments only (WRONG results; tools/ablate.sh): bit 0 g2p's gather without its LDS reads,
 // bit 1 g2p without the noise field, bit 2 g2p without its stores, bit 3 the momentum pass without its LDS
-// atomics, bit 4 the momentum pass without the mass reads of its density sum.
+// atomics, bit 4 the momentum pass without the mass reads of its density sum, bit 5 g2p with half of its
+// stores, bit 6 every arena access free of bank conflicts, bits 7 / 8 / 9 the mass pass without its LDS
+// atomics / without the global atomics of its flush / without marking the tiles it touched.
 #ifndef FLOWMPM_ABLATE
 #define FLOWMPM_ABLATE 0
 #endif
@@ -903,7 +905,11 @@ __device__ __forceinline__ void p2g_mass_particle(const Stencil &s, int *lds, in
             for (int gz = 0; gz < 3; gz++) {
                 int em = encode_fixed(wxy * s.wz[gz]);
                 if (INSIDE) {
+#if FLOWMPM_ABLATE & 128
+                    if (em == 0x7ABCDEF1) lds[abase] = 1;
+#else
                     atomicAdd(&lds[abase + arena_index(gx, gy, gz)], em);
+#endif
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     if (c >= 0) atomicAdd(g.mass + c, em);
@@ -964,9 +970,15 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         int v = lds[a];
         if (v == 0) continue;
         long long c = arena_cell_to_grid(a, A, P);
+#if FLOWMPM_ABLATE & 256
+        if (c == 0x7ABCDEF1) g.mass[0] = v;
+#else
         if (c >= 0) atomicAdd(g.mass + c, v);
+#endif
     }
+#if !(FLOWMPM_ABLATE & 512)
     mark_dirty_tiles(touched, item.x, w.td, g);
+#endif
     if (!counting) return;                                   // uniform
     // this workgroup's share of the 27 tile counters, then the ranks become ranks inside the tile
     if (threadIdx.x < 27 && nb_count[threadIdx.x] > 0) {
