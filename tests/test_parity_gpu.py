@@ -763,3 +763,34 @@ def test_every_form_of_the_rebin_gives_the_same_bits(oracle_binding, monkeypatch
         if sparse != "0":
             assert t["stragglers"] > 16 * 100, t      # the tail takes the follow-up kernels' path in every step
         h.close()
+
+
+@pytest.mark.gpu
+def test_two_thousand_steps_of_fast_particles_scatter_and_tiled_agree():
+    """A soak run of the device-decided re-bins: 200,000 particles that cross a tile every few steps, the
+    reference's default noise, 2,000 steps in calls of varying length with reads in between.  The tiled
+    algorithm (dozens of re-bins riding on steps, work items of every size, stragglers in every step) must
+    end on the bits of the reference's algorithm run as written."""
+    grid, n = (96, 64, 80), 200000
+    rec = moving_particles(n, grid, seed=404, vel=1.5)
+    uni = dict(DEFAULT_UNIFORMS, noise=1.0, rest_density=2.0)
+    outs, rebins = [], 0
+    for algo in (_lib.ALGO_SCATTER, _lib.ALGO_TILED):
+        h = _handle(grid, rec, algo, uniforms=uni, rebin_interval=64)
+        done = 0
+        for k, chunk in enumerate([1, 7, 192, 300, 500, 1000]):
+            h.step(chunk, 0.01)
+            h.set_uniforms(**dict(uni, time=(done + chunk) * 0.01))      # the clock goes on across the calls
+            done += chunk
+            if k % 2 == 0:
+                h.download_field(_lib.FIELD_POSITION)
+        assert done == 2000
+        outs.append((h.download_grid_i32(), h.download_grid_f32(), h.download_particles()))
+        if algo == _lib.ALGO_TILED:
+            rebins = h.timings()["rebin"]["performed"]
+        h.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert_bits_equal(outs[0][1], outs[1][1], "float grid scatter vs tiled")
+    assert_bits_equal(outs[0][2], outs[1][2], "particles scatter vs tiled")
+    assert np.isfinite(outs[1][2]).all()
+    assert rebins >= 20, rebins
