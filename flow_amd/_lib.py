@@ -47,8 +47,10 @@ EXPORTS = (
     "flowmpm_insert_arrivals", "flowmpm_set_mode_uniforms", "flowmpm_halo_words", "flowmpm_halo_pack",
     "flowmpm_halo_add", "flowmpm_find_leavers", "flowmpm_pack_leavers", "flowmpm_grid_sums",
     "flowmpm_set_domain_particles", "flowmpm_get_allocation_count",
-    "flowmpm_download_field_static",
+    "flowmpm_download_field_static", "flowmpm_generate_particles", "flowmpm_plane_histogram",
+    "flowmpm_stencil_mass_sum", "flowmpm_abi_sizes",
 )
+SCENE_ELLIPSOID, SCENE_DAM_BREAK = 0, 1
 
 
 class Config(ctypes.Structure):
@@ -173,11 +175,22 @@ def load():
         "flowmpm_pack_leavers": ([vp, i64p, i32, vp, i64], ctypes.c_int),
         "flowmpm_get_allocation_count": ([vp, i64p], ctypes.c_int),
         "flowmpm_download_field_static": ([vp, i32, fp, i64], ctypes.c_int),
+        "flowmpm_generate_particles": ([vp, i32, u32, i64, i64, ctypes.c_double, i64p], ctypes.c_int),
+        "flowmpm_plane_histogram": ([vp, i64p, i32], ctypes.c_int),
+        "flowmpm_stencil_mass_sum": ([vp, i64p], ctypes.c_int),
+        "flowmpm_abi_sizes": ([i64p], ctypes.c_int),
     }
     for name, (argtypes, restype) in protos.items():
         fn = getattr(L, name)
         fn.argtypes = argtypes
         fn.restype = restype
+    # the structs above are re-declarations of include/flowmpm.h: their sizes must be the library's
+    sizes = (ctypes.c_int64 * 4)()
+    L.flowmpm_abi_sizes(sizes)
+    mine = [ctypes.sizeof(t) for t in (Config, Uniforms, ModeUniforms, Timings)]
+    if list(sizes) != mine:
+        raise ImportError("flow_amd: struct layout mismatch with %s: library %r, binding %r"
+                          % (LIB_PATH, list(sizes), mine))
     _lib = L
     return L
 

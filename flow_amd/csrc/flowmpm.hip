@@ -21,6 +21,7 @@
 
 #include "kernels_scatter.h"
 #include "kernels_tiled.h"
+#include "kernels_scene.h"
 
 // ---- staging of flowmpm_download_field_static ------------------------------------------------
 // One array per GPU the library runs on, held until the process ends: the id-ordered values of one
@@ -512,12 +513,20 @@ int alloc_store(flowmpm_sim *s, int which)
     return FLOWMPM_OK;
 }
 
-// The handle's device staging buffer, at least `bytes` large.  Growing it frees the old one, which is
-// safe here: every user synchronises the stream before it returns.
-int stage_device(flowmpm_sim *s, size_t bytes, void **out)
+// The handle's device staging buffer holds at most this much: larger transfers (whole-store parity dumps,
+// the grids of a 512^3 domain) pass through it in chunks, so that one read-back never pins gigabytes of
+// device memory until flowmpm_destroy.
+constexpr size_t kDeviceStageMax = (size_t)256 << 20;
+
+// The handle's device staging buffer, min(bytes, kDeviceStageMax) large or more; *got receives its size.
+// Growing it frees the old one, which is safe here: every user synchronises the stream before it returns.
+// Small buffers (the per-frame reads of a renderer) grow geometrically, large ones to what is asked for.
+int stage_device(flowmpm_sim *s, size_t bytes, void **out, size_t *got = nullptr)
 {
-    if (s->stage_dev_bytes < bytes) {
-        const size_t want = (std::max(bytes, 2 * s->stage_dev_bytes) + 255) / 256 * 256;
+    const size_t need = std::min(bytes, kDeviceStageMax);
+    if (s->stage_dev_bytes < need) {
+        size_t want = need <= ((size_t)16 << 20) ? std::max(need, 2 * s->stage_dev_bytes) : need;
+        want = std::min(kDeviceStageMax, (want + 255) / 256 * 256);
         HIP_TRY(s, hipStreamSynchronize(s->stream));
         if (s->stage_dev) (void)hipFree(s->stage_dev);
         s->stage_dev = nullptr;
@@ -527,6 +536,7 @@ int stage_device(flowmpm_sim *s, size_t bytes, void **out)
         s->stage_allocations += 1;
     }
     *out = s->stage_dev;
+    if (got) *got = s->stage_dev_bytes;
     return FLOWMPM_OK;
 }
 
@@ -566,26 +576,35 @@ int copy_out_and_wait(flowmpm_sim *s, void *host_dst, const void *dev_src, size_
     return FLOWMPM_OK;
 }
 
-// Uploads `count` host records into slots [first_slot, first_slot + count).
+// Uploads `count` host records into slots [first_slot, first_slot + count), one staging buffer's worth
+// at a time.
 int upload_records(flowmpm_sim *s, const float *aos, const int32_t *ids, long long first_slot,
                    long long count)
 {
     if (count == 0) return FLOWMPM_OK;
-    const size_t aos_bytes = (size_t)count * 28 * sizeof(float), id_bytes = ids ? (size_t)count * sizeof(int) : 0;
+    const size_t row_bytes = 28 * sizeof(float) + (ids ? sizeof(int) : 0);
     void *stage = nullptr;
-    int rc = stage_device(s, aos_bytes + id_bytes, &stage);
+    size_t got = 0;
+    int rc = stage_device(s, (size_t)count * row_bytes, &stage, &got);
     if (rc) return rc;
-    float *d_aos = static_cast<float *>(stage);
-    int *d_ids = ids ? reinterpret_cast<int *>(static_cast<char *>(stage) + aos_bytes) : nullptr;
-    hipError_t e = hipMemcpyAsync(d_aos, aos, aos_bytes, hipMemcpyHostToDevice, s->stream);
-    if (e == hipSuccess && ids) e = hipMemcpyAsync(d_ids, ids, id_bytes, hipMemcpyHostToDevice, s->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(mpm::aos_to_soa_kernel, dim3(blocks_for(count, 256)), dim3(256), 0, s->stream,
-                           d_aos, d_ids, s->store, first_slot, count);
-        e = hipGetLastError();
+    const long long rows_max = std::max<long long>(1, (long long)(got / row_bytes));
+    for (long long lo = 0; lo < count; lo += rows_max) {
+        const long long rows = std::min(rows_max, count - lo);
+        const size_t aos_bytes = (size_t)rows * 28 * sizeof(float);
+        float *d_aos = static_cast<float *>(stage);
+        int *d_ids = ids ? reinterpret_cast<int *>(static_cast<char *>(stage) + aos_bytes) : nullptr;
+        hipError_t e = hipMemcpyAsync(d_aos, aos + lo * 28, aos_bytes, hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess && ids)
+            e = hipMemcpyAsync(d_ids, ids + lo, (size_t)rows * sizeof(int), hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(mpm::aos_to_soa_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, s->stream,
+                               d_aos, d_ids, s->store, first_slot + lo, rows, ids ? 0LL : lo);
+            e = hipGetLastError();
+        }
+        // the next chunk overwrites the staging buffer, and the caller's arrays are pageable
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-    if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
     return FLOWMPM_OK;
 }
 
@@ -775,6 +794,125 @@ int flowmpm_upload_particles(flowmpm_sim *s, const float *aos, const int32_t *id
     return FLOWMPM_OK;
 }
 
+// The host loop of init() (SIM:114-129) on the device; see kernels_scene.h.
+int flowmpm_generate_particles(flowmpm_sim *s, int32_t scene, uint32_t seed, int64_t first_id, int64_t count,
+                               double fill, int64_t *stored)
+{
+    CHECK_SIM(s);
+    if (stored) *stored = 0;
+    if (scene != FLOWMPM_SCENE_ELLIPSOID && scene != FLOWMPM_SCENE_DAM_BREAK)
+        return fail(s, FLOWMPM_ERR_INVALID, "unknown scene");
+    if (count < 0 || first_id < 0 || first_id + count > 2147483647LL)
+        return fail(s, FLOWMPM_ERR_INVALID, "particle ids must fit 31 bits");
+    if (!s->slab && first_id != 0)
+        return fail(s, FLOWMPM_ERR_INVALID, "a single-domain handle holds the ids 0 .. count - 1");
+    if (!s->slab && count > s->cfg.max_particles)
+        return fail(s, FLOWMPM_ERR_CAPACITY, "more particles than max_particles");
+    if (scene == FLOWMPM_SCENE_DAM_BREAK && !(fill > 0.0 && fill <= 1.0))
+        return fail(s, FLOWMPM_ERR_INVALID, "the dam-break column needs 0 < fill <= 1");
+    // SIM:90-112: the palette as hex strings, converted as the reference does (parseInt / 255)
+    static const unsigned char palette[13][3] = {
+        {0xFF, 0x56, 0xB7}, {0xBC, 0x96, 0xF9}, {0xC5, 0xF0, 0xF2}, {0x00, 0x74, 0x87}, {0x00, 0x74, 0x87},
+        {0x15, 0x39, 0x43}, {0x23, 0x23, 0x56}, {0x50, 0x12, 0x1A}, {0xFF, 0x64, 0x25}, {0xD6, 0xF4, 0x99},
+        {0x5C, 0xCA, 0xD8}, {0x5C, 0xCA, 0xD8}, {0xC5, 0xF0, 0xF2}};
+    mpm::SceneSpec sp{};
+    sp.kind = scene == FLOWMPM_SCENE_ELLIPSOID ? mpm::kSceneEllipsoid : mpm::kSceneDamBreak;
+    sp.seed = seed;
+    sp.first_id = first_id;
+    sp.count = count;
+    sp.gx = s->cfg.grid_x; sp.gy = s->cfg.grid_y; sp.gz = s->cfg.grid_z;
+    sp.fill = fill;
+    for (int c = 0; c < 13; c++)
+        for (int k = 0; k < 3; k++) sp.palette[c][k] = (float)((double)palette[c][k] / 255.0);
+    sp.keep_lo = s->cfg.slab_x0;
+    sp.keep_hi = s->cfg.slab_x0 + s->cfg.slab_nx;
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    long long kept = count;
+    if (count > 0) {
+        int *counter = nullptr;
+        if (s->slab) {
+            void *stage = nullptr;
+            int rc = stage_device(s, sizeof(int), &stage);
+            if (rc) return rc;
+            counter = static_cast<int *>(stage);
+            HIP_TRY(s, hipMemsetAsync(counter, 0, sizeof(int), s->stream));
+        }
+        const unsigned blocks = (unsigned)std::min<long long>(blocks_for(count, 256), 16384);
+        hipLaunchKernelGGL(mpm::generate_scene_kernel, dim3(blocks), dim3(256), 0, s->stream, sp, s->store, 0LL,
+                           (long long)s->cfg.max_particles, counter);
+        int rc = launch_check(s, "generate_scene");
+        if (rc) return rc;
+        if (counter) {
+            int host_count = 0;
+            if ((rc = copy_out_and_wait(s, &host_count, counter, sizeof(int), "generate_scene"))) return rc;
+            kept = host_count;
+        } else {
+            HIP_TRY(s, hipStreamSynchronize(s->stream));
+        }
+    }
+    s->shadow.clear();
+    s->tiled.valid = false;
+    s->tiles_marked = false;
+    s->tiled.listed = -1;
+    s->stayers_done = false;
+    s->arrivals_first = -1;
+    s->migration.classified = -1;
+    if (kept > s->cfg.max_particles) {
+        s->resident = s->live = s->uploaded = 0;
+        char buf[160];
+        snprintf(buf, sizeof buf, "%lld of the generated particles fall into this slab, max_particles is %lld",
+                 kept, (long long)s->cfg.max_particles);
+        return fail(s, FLOWMPM_ERR_CAPACITY, buf);
+    }
+    s->resident = s->live = s->uploaded = kept;
+    if (stored) *stored = kept;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_plane_histogram(flowmpm_sim *s, int64_t *out, int32_t planes)
+{
+    CHECK_SIM(s);
+    if (!out || planes != s->cfg.grid_x) return fail(s, FLOWMPM_ERR_INVALID, "the histogram has grid_x entries");
+    if (planes > mpm::kHistPlanes) return fail(s, FLOWMPM_ERR_UNSUPPORTED, "plane histogram: grid_x above 8192");
+    void *stage = nullptr;
+    int rc = stage_device(s, (size_t)planes * sizeof(unsigned long long), &stage);
+    if (rc) return rc;
+    HIP_TRY(s, hipMemsetAsync(stage, 0, (size_t)planes * sizeof(unsigned long long), s->stream));
+    if (s->resident > 0) {
+        hipLaunchKernelGGL(mpm::plane_histogram_kernel, dim3((unsigned)std::min<long long>(blocks_for(s->resident, 256), 1024)),
+                           dim3(256), 0, s->stream, s->store, (long long)s->resident, (int)planes,
+                           static_cast<unsigned long long *>(stage));
+        if ((rc = launch_check(s, "plane_histogram"))) return rc;
+    }
+    return copy_out_and_wait(s, out, stage, (size_t)planes * sizeof(int64_t), "plane_histogram");
+}
+
+int flowmpm_stencil_mass_sum(flowmpm_sim *s, int64_t *out)
+{
+    CHECK_SIM(s);
+    if (!out) return fail(s, FLOWMPM_ERR_INVALID, "null output");
+    void *stage = nullptr;
+    int rc = stage_device(s, sizeof(unsigned long long), &stage);
+    if (rc) return rc;
+    HIP_TRY(s, hipMemsetAsync(stage, 0, sizeof(unsigned long long), s->stream));
+    if (s->resident > 0) {
+        hipLaunchKernelGGL(mpm::stencil_mass_sum_kernel, dim3(2048), dim3(256), 0, s->stream, s->store,
+                           (long long)s->resident, static_cast<unsigned long long *>(stage));
+        if ((rc = launch_check(s, "stencil_mass_sum"))) return rc;
+    }
+    return copy_out_and_wait(s, out, stage, sizeof(int64_t), "stencil_mass_sum");
+}
+
+int flowmpm_abi_sizes(int64_t sizes[4])
+{
+    if (!sizes) return fail(nullptr, FLOWMPM_ERR_INVALID, "null output");
+    sizes[0] = (int64_t)sizeof(flowmpm_config);
+    sizes[1] = (int64_t)sizeof(flowmpm_uniforms);
+    sizes[2] = (int64_t)sizeof(flowmpm_mode_uniforms);
+    sizes[3] = (int64_t)sizeof(flowmpm_timings);
+    return FLOWMPM_OK;
+}
+
 int flowmpm_set_domain_particles(flowmpm_sim *s, int64_t count)
 {
     CHECK_SIM(s);
@@ -887,20 +1025,27 @@ int flowmpm_download_particles(flowmpm_sim *s, float *aos, int32_t *ids, int64_t
     if (total == 0) return FLOWMPM_OK;
     const long long n = s->resident;
     if (n > 0) {
-        const size_t aos_bytes = (size_t)n * 28 * sizeof(float), id_bytes = s->slab ? (size_t)n * sizeof(int) : 0;
+        // a window of rows at a time: rows are particle ids on a single-domain handle, slots on a slab
+        const size_t row_bytes = 28 * sizeof(float) + (s->slab ? sizeof(int) : 0);
         void *stage = nullptr;
-        int rc = stage_device(s, aos_bytes + id_bytes, &stage);
+        size_t got = 0;
+        int rc = stage_device(s, (size_t)n * row_bytes, &stage, &got);
         if (rc) return rc;
-        float *d_aos = static_cast<float *>(stage);
-        int *d_ids = s->slab ? reinterpret_cast<int *>(static_cast<char *>(stage) + aos_bytes) : nullptr;
-        hipLaunchKernelGGL(mpm::soa_to_aos_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->store,
-                           n, d_aos, d_ids, s->slab ? 0 : 1);
-        if ((rc = launch_check(s, "soa_to_aos"))) return rc;
-        if (s->slab && ids) {
-            hipError_t e = hipMemcpyAsync(ids, d_ids, id_bytes, hipMemcpyDeviceToHost, s->stream);
-            if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("download ids: ") + hipGetErrorString(e));
+        const long long rows_max = std::max<long long>(1, (long long)(got / row_bytes));
+        for (long long lo = 0; lo < n; lo += rows_max) {
+            const long long rows = std::min(rows_max, n - lo);
+            const size_t aos_bytes = (size_t)rows * 28 * sizeof(float);
+            float *d_aos = static_cast<float *>(stage);
+            int *d_ids = s->slab ? reinterpret_cast<int *>(static_cast<char *>(stage) + aos_bytes) : nullptr;
+            hipLaunchKernelGGL(mpm::soa_to_aos_kernel, dim3(blocks_for(s->slab ? rows : n, 256)), dim3(256), 0, s->stream,
+                               s->store, s->slab ? lo + rows : n, d_aos, d_ids, s->slab ? 0 : 1, lo, rows);
+            if ((rc = launch_check(s, "soa_to_aos"))) return rc;
+            if (s->slab && ids) {
+                hipError_t e = hipMemcpyAsync(ids + lo, d_ids, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost, s->stream);
+                if (e != hipSuccess) return fail(s, FLOWMPM_ERR_HIP, std::string("download ids: ") + hipGetErrorString(e));
+            }
+            if ((rc = copy_out_and_wait(s, aos + lo * 28, d_aos, aos_bytes, "download"))) return rc;
         }
-        if ((rc = copy_out_and_wait(s, aos, d_aos, aos_bytes, "download"))) return rc;
     }
     if (!s->slab && s->uploaded > s->resident)   // records beyond the live count are host-held
         memcpy(aos + s->resident * 28, s->shadow.data(), (size_t)(s->uploaded - s->resident) * 28 * sizeof(float));
@@ -952,11 +1097,18 @@ int flowmpm_download_field(flowmpm_sim *s, int32_t field, float *out, int64_t ca
     if (!out || capacity < n) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
     if (n == 0) return FLOWMPM_OK;
     void *stage = nullptr;
-    if ((rc = stage_device(s, (size_t)n * width * sizeof(float), &stage))) return rc;
-    hipLaunchKernelGGL(mpm::gather_field_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->store, n,
-                       slot, width, static_cast<float *>(stage));
-    if ((rc = launch_check(s, "gather_field"))) return rc;
-    return copy_out_and_wait(s, out, stage, (size_t)n * width * sizeof(float), "download_field");
+    size_t got = 0;
+    if ((rc = stage_device(s, (size_t)n * width * sizeof(float), &stage, &got))) return rc;
+    const long long ids_max = std::max<long long>(1, (long long)(got / (width * sizeof(float))));
+    for (long long lo = 0; lo < n; lo += ids_max) {
+        const long long ids = std::min(ids_max, n - lo);
+        hipLaunchKernelGGL(mpm::gather_field_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->store, n,
+                           slot, width, static_cast<float *>(stage), lo, ids);
+        if ((rc = launch_check(s, "gather_field"))) return rc;
+        if ((rc = copy_out_and_wait(s, out + lo * width, stage, (size_t)ids * width * sizeof(float), "download_field")))
+            return rc;
+    }
+    return FLOWMPM_OK;
 }
 
 // flowmpm_download_field without any allocation: the id-ordered values are staged in this device's
@@ -980,7 +1132,7 @@ int flowmpm_download_field_static(flowmpm_sim *s, int32_t field, float *out, int
     float *stage = s->static_field;
     if (!stage) return fail(s, FLOWMPM_ERR_HIP, "the static staging array was not set up on this device");
     hipLaunchKernelGGL(mpm::gather_field_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s->stream, s->store, n,
-                       slot, width, stage);
+                       slot, width, stage, 0LL, n);
     if ((rc = launch_check(s, "gather_field"))) return rc;
     HIP_TRY(s, hipMemcpyAsync(out, stage, (size_t)n * width * sizeof(float), hipMemcpyDefault, s->stream));
     HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -1001,12 +1153,18 @@ int flowmpm_download_grid_i32(flowmpm_sim *s, int32_t *out, int64_t capacity_cel
     if (!out || capacity_cells < s->local_cells) return fail(s, FLOWMPM_ERR_INVALID, "output array too small");
     // The device keeps the mass words apart; hosts get the reference's {x, y, z, mass} records.
     void *stage = nullptr;
-    int rc = stage_device(s, (size_t)s->local_cells * sizeof(int4), &stage);
+    size_t got = 0;
+    int rc = stage_device(s, (size_t)s->local_cells * sizeof(int4), &stage, &got);
     if (rc) return rc;
-    hipLaunchKernelGGL(mpm::assemble_cells_kernel, dim3(blocks_for(s->local_cells, 256)), dim3(256), 0, s->stream,
-                       s->cell, s->mass_i, static_cast<int4 *>(stage), s->local_cells);
-    if ((rc = launch_check(s, "assemble_cells"))) return rc;
-    return copy_out_and_wait(s, out, stage, (size_t)s->local_cells * sizeof(int4), "download_grid_i32");
+    const long long cells_max = std::max<long long>(1, (long long)(got / sizeof(int4)));
+    for (long long lo = 0; lo < s->local_cells; lo += cells_max) {
+        const long long cells = std::min(cells_max, s->local_cells - lo);
+        hipLaunchKernelGGL(mpm::assemble_cells_kernel, dim3(blocks_for(cells, 256)), dim3(256), 0, s->stream,
+                           s->cell + lo, s->mass_i + lo, static_cast<int4 *>(stage), cells);
+        if ((rc = launch_check(s, "assemble_cells"))) return rc;
+        if ((rc = copy_out_and_wait(s, out + lo * 4, stage, (size_t)cells * sizeof(int4), "download_grid_i32"))) return rc;
+    }
+    return FLOWMPM_OK;
 }
 
 int flowmpm_download_grid_f32(flowmpm_sim *s, float *out, int64_t capacity_cells)

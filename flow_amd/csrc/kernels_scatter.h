@@ -283,10 +283,11 @@ g2p_gather_kernel(StoreSel ss, long long n, const float4 *__restrict__ cellf, Pa
     st.slot(kDirX)[j] = o.dirx; st.slot(kDirY)[j] = o.diry; st.slot(kDirZ)[j] = o.dirz;
 }
 
-// Host AoS record (28 floats, the reference's layout) <-> SoA store.
+// Host AoS record (28 floats, the reference's layout) <-> SoA store.  Without `ids`, record i becomes
+// particle id_base + i.
 __global__ void __launch_bounds__(256)
 aos_to_soa_kernel(const float *__restrict__ aos, const int *__restrict__ ids, StoreSel ss,
-                  long long first_slot, long long count)
+                  long long first_slot, long long count, long long id_base)
 {
     const Store st = ss.pick();
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -303,20 +304,25 @@ aos_to_soa_kernel(const float *__restrict__ aos, const int *__restrict__ ids, St
         for (int row = 0; row < 3; row++) st.slot(kC00 + 3 * c + row)[j] = r[8 + 4 * c + row];
     st.slot(kDirX)[j] = r[20]; st.slot(kDirY)[j] = r[21]; st.slot(kDirZ)[j] = r[22];
     st.slot(kColR)[j] = r[24]; st.slot(kColG)[j] = r[25]; st.slot(kColB)[j] = r[26];
-    st.ids()[j] = ids ? ids[i] : (int)i;
+    st.ids()[j] = ids ? ids[i] : (int)(id_base + i);
 }
 
-// dst_by_id != 0: record of the particle in slot j goes to row ids[j] (id order);
-// otherwise to row j, and ids_out[j] receives its id.
+// dst_by_id != 0: record of the particle in slot j goes to row ids[j] (id order); otherwise to row j,
+// and ids_out receives its id.  Only rows [row_lo, row_lo + rows) are written, to aos[(row - row_lo) * 28]
+// (and ids_out[row - row_lo]): a large store is read back through a staging buffer of fixed size, one
+// window of rows at a time.  In id order every window scans all `count` slots; in slot order a window
+// visits its own slots only.
 __global__ void __launch_bounds__(256)
 soa_to_aos_kernel(StoreSel ss, long long count, float *__restrict__ aos, int *__restrict__ ids_out,
-                  int dst_by_id)
+                  int dst_by_id, long long row_lo, long long rows)
 {
     const Store st = ss.pick();
-    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long j = (dst_by_id ? 0 : row_lo) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     int id = st.ids()[j];
-    float *r = aos + (dst_by_id ? (long long)id : j) * 28;
+    const long long row = (dst_by_id ? (long long)id : j) - row_lo;
+    if (row < 0 || row >= rows) return;
+    float *r = aos + row * 28;
     r[0] = st.slot(kPosX)[j]; r[1] = st.slot(kPosY)[j]; r[2] = st.slot(kPosZ)[j];
     r[3] = st.slot(kDensity)[j];
     r[4] = st.slot(kVelX)[j]; r[5] = st.slot(kVelY)[j]; r[6] = st.slot(kVelZ)[j];
@@ -324,25 +330,28 @@ soa_to_aos_kernel(StoreSel ss, long long count, float *__restrict__ aos, int *__
 #pragma unroll
     for (int c = 0; c < 3; c++) {
 #pragma unroll
-        for (int row = 0; row < 3; row++) r[8 + 4 * c + row] = st.slot(kC00 + 3 * c + row)[j];
+        for (int row3 = 0; row3 < 3; row3++) r[8 + 4 * c + row3] = st.slot(kC00 + 3 * c + row3)[j];
         r[8 + 4 * c + 3] = 0.0f;
     }
     r[20] = st.slot(kDirX)[j]; r[21] = st.slot(kDirY)[j]; r[22] = st.slot(kDirZ)[j];
     r[23] = 0.0f;
     r[24] = st.slot(kColR)[j]; r[25] = st.slot(kColG)[j]; r[26] = st.slot(kColB)[j];
     r[27] = 0.0f;
-    if (ids_out) ids_out[j] = id;
+    if (ids_out) ids_out[row] = id;
 }
 
-// One per-particle field in id order (what a renderer binds).
+// One per-particle field in id order (what a renderer binds): the values of ids [id_lo, id_lo + ids)
+// go to out[(id - id_lo) * width].
 __global__ void __launch_bounds__(256)
-gather_field_kernel(StoreSel ss, long long count, int first_slot, int width, float *__restrict__ out)
+gather_field_kernel(StoreSel ss, long long count, int first_slot, int width, float *__restrict__ out,
+                    long long id_lo, long long ids)
 {
     const Store st = ss.pick();
     long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    long long id = st.ids()[j];
-    for (int k = 0; k < width; k++) out[id * width + k] = st.slot(first_slot + k)[j];
+    const long long row = (long long)st.ids()[j] - id_lo;
+    if (row < 0 || row >= ids) return;
+    for (int k = 0; k < width; k++) out[row * width + k] = st.slot(first_slot + k)[j];
 }
 
 // Halo merge of the slab decomposition: dst.comp += src.comp (wrapping i32).

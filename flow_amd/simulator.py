@@ -74,6 +74,28 @@ class Handle:
             idp = _ip(ids)
         self._chk(self.L.flowmpm_upload_particles(self._h, _fp(rec), idp, rec.shape[0]))
 
+    def generate_particles(self, scene, count, seed=0xF10E5EED, first_id=0, fill=0.25):
+        """The seeded scene of flow_amd.particles (`reference_scene` / `dam_break`) generated on the
+        device, bit-identical to the host records.  Returns the number of particles stored (a slab
+        handle keeps those of its own planes)."""
+        stored = ctypes.c_int64()
+        self._chk(self.L.flowmpm_generate_particles(self._h, int(scene), int(seed) & 0xFFFFFFFF, int(first_id),
+                                                    int(count), float(fill), ctypes.byref(stored)))
+        return stored.value
+
+    def plane_histogram(self):
+        """Resident particles per x-plane of the global grid (int64[grid_x])."""
+        out = np.zeros(self.grid[0], dtype=np.int64)
+        self._chk(self.L.flowmpm_plane_histogram(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                                 self.grid[0]))
+        return out
+
+    def stencil_mass_sum(self):
+        """Sum of encodeFixedPoint(weight) over the resident particles' stencils, from the positions."""
+        out = ctypes.c_int64()
+        self._chk(self.L.flowmpm_stencil_mass_sum(self._h, ctypes.byref(out)))
+        return out.value
+
     def set_num_particles(self, n):
         self._chk(self.L.flowmpm_set_num_particles(self._h, int(n)))
 

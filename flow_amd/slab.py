@@ -57,6 +57,14 @@ def balanced_plane_starts(x_positions, grid_x, world, dist=None, device=None):
             t = t.to(device)
         dist.all_reduce(t)
         hist = t.cpu().numpy()
+    return plane_starts_from_histogram(hist, world)
+
+
+def plane_starts_from_histogram(hist, world):
+    """The balanced cut from the particles-per-plane histogram of the whole domain (what
+    flowmpm_plane_histogram returns, summed over the slabs)."""
+    hist = np.asarray(hist, dtype=np.int64)
+    grid_x = hist.shape[0]
     cum = np.cumsum(hist)
     total = int(cum[-1])
     starts = [0]
@@ -523,3 +531,105 @@ class SlabSimulation:
 
     def close(self):
         self.backend.close()
+
+
+class LocalSlabGroup:
+    """All slabs of a decomposition driven by ONE process in lock-step on one device: the stage order of
+    SlabSimulation.step() (the mass pass split around the migration, momentum pass and g2p in an
+    interior and a boundary launch around the halo merges) with device buffers handed from slab to
+    slab in place of a transport.  Every handle enqueues on the same stream, so the order of the calls
+    is the order on the device.  What the full-size decomposition tests and the single-GPU slab
+    measurements run on; results equal the single domain's bit for bit, as with any transport."""
+
+    def __init__(self, grid, plane_starts, max_particles, device=0, rebin_interval=64):
+        import torch
+        self.torch = torch
+        self.grid = tuple(int(g) for g in grid)
+        self.plane_starts = [int(x) for x in plane_starts]
+        self.world = len(self.plane_starts) - 1
+        caps = max_particles if hasattr(max_particles, "__len__") else [max_particles] * self.world
+        self.backends = [GpuSlabBackend(self.grid, self.plane_starts[r], self.plane_starts[r + 1] - self.plane_starts[r],
+                                        int(caps[r]), device, _lib.ALGO_TILED, rebin_interval)
+                         for r in range(self.world)]
+        self.handles = [b.handle for b in self.backends]
+        masks = (_lib.COMP_MASS, _lib.COMP_MOMENTUM)
+        self._halo = [{(side, m): b.new_halo_buffer(m) for side in (_lib.SIDE_LOW, _lib.SIDE_HIGH) for m in masks}
+                      for b in self.backends]
+        self._pending = False
+        self.migrated = 0
+        self.max_hop = 0
+
+    def set_uniforms(self, **kw):
+        for b in self.backends:
+            b.set_uniforms(**kw)
+
+    def _run(self, kernel_id):
+        for b in self.backends:
+            b.run_kernel(kernel_id)
+
+    def _pack(self, mask):
+        for r, b in enumerate(self.backends):
+            if r > 0:
+                b.halo_pack(_lib.SIDE_LOW, mask, self._halo[r][_lib.SIDE_LOW, mask])
+            if r < self.world - 1:
+                b.halo_pack(_lib.SIDE_HIGH, mask, self._halo[r][_lib.SIDE_HIGH, mask])
+
+    def _add(self, mask):
+        for r, b in enumerate(self.backends):
+            if r > 0:          # my LOW pair is the low neighbour's HIGH pair
+                b.halo_add(_lib.SIDE_LOW, mask, self._halo[r - 1][_lib.SIDE_HIGH, mask])
+            if r < self.world - 1:
+                b.halo_add(_lib.SIDE_HIGH, mask, self._halo[r + 1][_lib.SIDE_LOW, mask])
+
+    def _migrate(self):
+        if not self._pending:
+            return
+        self._pending = False
+        for b in self.backends:
+            b.refind_leavers(self.plane_starts)
+        matrix = self.torch.stack([b._counts for b in self.backends]).cpu().numpy()      # the one host wait
+        packed = [b.pack_leavers(matrix[r]) for r, b in enumerate(self.backends)]
+        for r in range(self.world):
+            offs = np.concatenate([[0], np.cumsum(matrix[r])])
+            for peer in np.nonzero(matrix[r])[0]:
+                self.migrated += int(matrix[r, peer])
+                self.max_hop = max(self.max_hop, abs(int(peer) - r))
+                self.backends[peer].insert_arrivals(packed[r][int(offs[peer]):int(offs[peer + 1])])
+
+    def step(self):
+        self._run(_lib.KERNEL_CLEAR_FIXED_GRID)
+        self._run(_lib.KERNEL_P2G_MASS_STAYERS)
+        self._migrate()
+        self._run(_lib.KERNEL_P2G_MASS_ARRIVALS)
+        self._pack(_lib.COMP_MASS)
+        self._run(_lib.KERNEL_P2G_MOMENTUM_INTERIOR)
+        self._add(_lib.COMP_MASS)
+        self._run(_lib.KERNEL_P2G_MOMENTUM_BOUNDARY)
+        self._pack(_lib.COMP_MOMENTUM)
+        self._run(_lib.KERNEL_UPDATE_GRID)
+        self._run(_lib.KERNEL_G2P_INTERIOR)
+        self._add(_lib.COMP_MOMENTUM)
+        self._run(_lib.KERNEL_UPDATE_GRID_BOUNDARY)
+        self._run(_lib.KERNEL_G2P_BOUNDARY)
+        for b in self.backends:
+            b.find_leavers(self.plane_starts)
+        self._pending = True
+
+    def finish(self):
+        """Completes the migration of the last step; the particles then sit on their owners."""
+        self._migrate()
+        for b in self.backends:
+            b.synchronize()
+
+    def residents(self):
+        self._migrate()
+        return [b.resident() for b in self.backends]
+
+    def conservation(self):
+        """[grid x, y, z momentum words, grid mass words, particles] summed over the slabs."""
+        self._migrate()
+        return sum(np.concatenate([b.grid_sums(), [b.resident()]]).astype(np.int64) for b in self.backends)
+
+    def close(self):
+        for b in self.backends:
+            b.close()

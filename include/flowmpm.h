@@ -221,6 +221,20 @@ const char *flowmpm_last_error(const flowmpm_sim *sim);   /* sim may be NULL: la
  * particles for that slab are passed, with their global ids in `ids` (NULL: 0..count-1). */
 int flowmpm_upload_particles(flowmpm_sim *sim, const float *aos, const int32_t *ids,
                              int64_t count);
+/* The host loop of init() that fills the particle buffer (SIM:114-129), run on the device with the
+ * seeded counter-based generator of the hosts (flow_amd/particles.py, host_js/particles.js) in place of
+ * Math.random: the particles with ids [first_id, first_id + count) of scene `scene`, bit-identical to the
+ * hosts' records, replace the handle's particles.  For domains whose records would not fit host memory
+ * comfortably (2^27 particles are 15 GB of AoS records).  A single-domain handle takes first_id = 0 and
+ * stores particle i in slot i; a slab handle keeps the particles whose floor(x) lies in its owned planes,
+ * in no particular order (results never depend on the order).  *stored (may be NULL) receives the
+ * number kept.  FLOWMPM_SCENE_DAM_BREAK (no reference counterpart; benchmark configuration 5) spreads
+ * the particles uniformly over x in [3, fill * grid_x], y in [3, grid_y - 3], z in [3, grid_z - 3];
+ * `fill` is ignored by the ellipsoid. */
+#define FLOWMPM_SCENE_ELLIPSOID 0   /* SIM:114-129 */
+#define FLOWMPM_SCENE_DAM_BREAK 1
+int flowmpm_generate_particles(flowmpm_sim *sim, int32_t scene, uint32_t seed, int64_t first_id,
+                               int64_t count, double fill, int64_t *stored);
 /* uniforms.numParticles / dispatch counts (SIM:2513-2522): simulate the first
  * `count` particle ids only.  Single-GPU handles only. */
 int flowmpm_set_num_particles(flowmpm_sim *sim, int64_t count);
@@ -266,6 +280,21 @@ int flowmpm_download_grid_f32(flowmpm_sim *sim, float *out, int64_t capacity_cel
  * decomposed run it equals the single-GPU value. */
 int flowmpm_grid_sums(flowmpm_sim *sim, int64_t sums[4]);
 
+/* The same check from the particles' side: the sum over the resident particles and their 27 stencil
+ * cells of encodeFixedPoint(weight) (SIM:279-281, 329), in 64 bits, computed from the positions alone.
+ * Taken before a step it equals the mass word of flowmpm_grid_sums after that step's p2g (summed over
+ * the slabs of a decomposed run). */
+int flowmpm_stencil_mass_sum(flowmpm_sim *sim, int64_t *sum);
+/* Resident particles per x-plane of the global grid: out[ix] = particles with floor(position.x) = ix,
+ * `planes` = grid_x entries (at most 8192).  What a host cuts balanced slabs from (summed over the
+ * slabs of a decomposed run). */
+int flowmpm_plane_histogram(flowmpm_sim *sim, int64_t *out, int32_t planes);
+
+/* sizeof of the public structs as this library was compiled: flowmpm_config, flowmpm_uniforms,
+ * flowmpm_mode_uniforms, flowmpm_timings.  A binding that re-declares them (ctypes, a typed-array
+ * packer) checks its own layout against these at load time. */
+int flowmpm_abi_sizes(int64_t sizes[4]);
+
 /* Per-kernel device timing: HIP events attached to the kernel dispatches on the handle's
  * stream (start and end timestamps of the kernel itself).  every_nth_step = 0 switches it
  * off, 1 times every launch, k > 1 times the launches of every k-th step of flowmpm_step
@@ -285,15 +314,16 @@ int flowmpm_reset_timings(flowmpm_sim *sim);
  * flowmpm_create; it stops growing once the buffers have reached the size of the largest transfer. */
 int flowmpm_get_allocation_count(flowmpm_sim *sim, int64_t *count);
 
-/* flowmpm_download_field for callers that cannot allocate (code under HIP graph capture, tight
- * per-frame loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
- * arguments and results as flowmpm_download_field, but the id-ordered values are staged in a static
- * device array of the library (3 MiB per GPU the library has created a handle on, held until the
- * process ends) instead of the handle's staging buffer, and nothing is allocated or freed: `out` may
- * be device memory, pinned host memory, or pageable host memory (which the HIP runtime stages through
- * its own pool).  At most 262,144 live particles (conf.maxParticles, src/conf.js:8); more is
- * FLOWMPM_ERR_CAPACITY.  All handles on one GPU share that GPU's array: calls that overlap in time on
- * one GPU race; calls from one host thread never overlap, because each waits for its copy. */
+/* flowmpm_download_field for callers that cannot allocate (tight per-frame loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  Same arguments and results as flowmpm_download_field,
+ * but the id-ordered values are staged in a static device array of the library (3 MiB per GPU the
+ * library has created a handle on, held until the process ends) instead of the handle's staging buffer,
+ * and nothing is allocated or freed: `out` may be device memory, pinned host memory, or pageable host
+ * memory (which the HIP runtime stages through its own pool).  The call waits for its copy (it
+ * synchronises the handle's stream), so it cannot be recorded into a HIP graph.  At most 262,144 live
+ * particles (conf.maxParticles, src/conf.js:8); more is FLOWMPM_ERR_CAPACITY.  All handles on one GPU
+ * share that GPU's array: calls that overlap in time on one GPU race; calls from one host thread never
+ * overlap, because each waits for its copy. */
 int flowmpm_download_field_static(flowmpm_sim *sim, int32_t field, float *out, int64_t capacity);
 
 /* ---- Slab decomposition (no reference counterpart: the reference is single-GPU).
