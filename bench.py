@@ -243,12 +243,17 @@ def run_single(args):
     # FLOWMPM_BENCH_PAD: extra particle slots, for experiments with the stride between the store's columns
     h = flow_amd.Handle(grid, n + int(os.environ.get("FLOWMPM_BENCH_PAD", "0")), device=0, algorithm=algo,
                         rebin_interval=args.rebin_interval)
-    rec = make_particles(args.scene, n, grid, seed)
+    # The scene is generated on the device (flowmpm_generate_particles: the hosts' seeded generator, bit for
+    # bit), so that the run is not tens of seconds of numpy around half a second of GPU work.
+    kind = _lib.SCENE_ELLIPSOID if args.scene == "ellipsoid" else _lib.SCENE_DAM_BREAK
+    h.generate_particles(kind, n, seed=seed, fill=0.25)
     max_per_cell = None
     if args.scene == "dam_break":        # how crowded the column starts out
-        ix = np.floor(rec[:, 0:3]).astype(np.int64)
+        ix = np.floor(h.download_field(_lib.FIELD_POSITION)).astype(np.int64)
         max_per_cell = int(np.bincount((ix[:, 0] * grid[1] + ix[:, 1]) * grid[2] + ix[:, 2]).max())
-    h.upload_particles(rec)
+        del ix
+    want_cpu = not args.no_cpu_baseline and args.mode == "chaos"
+    rec = h.download_particles() if want_cpu else None      # the CPU baseline runs on the same particles
     if args.mode != "chaos":
         mode_uni, mode_record = mode_setup(args.mode, grid, n)
         uniforms = dict(uniforms, **mode_uni)
@@ -307,7 +312,7 @@ def run_single(args):
         steady = {"value": round(med, 1), "unit": "particle-substeps/s", "ms_per_step": round(n / med * 1e3, 4),
                   "steps": steady_steps, "windows": [round(v, 1) for v in window_values],
                   "min": round(min(window_values), 1), "rebins": rebins,
-                  "rebin_ms_per_step": round(rebin_ms / steady_steps, 4),
+                  "rebin_ms_per_step": round(rebin_ms / steady_steps, 4),       # the scan launches only (see kernels.p2g_with_sort)
                   "stragglers_per_step": round(((after["rebin"].get("stragglers") or 0)
                                                 - (before["rebin"].get("stragglers") or 0)) / steady_steps, 1)}
         steady_kernels = {name: {"ms": after[name]["ms"] - before[name]["ms"],
@@ -315,11 +320,26 @@ def run_single(args):
         steady["kernel_avg_ms"] = {name: round(t["ms"] / t["launches"], 4)
                                    for name, t in steady_kernels.items() if t["launches"]}
     h.close()
-    roof, per_kernel = roofline_of(timings, n, cells)
+    first_roof, per_kernel = roofline_of(timings, n, cells)
+    # The line's roofline is the steady one whenever the steady windows ran: the timed window follows a
+    # fresh binning by a few steps and holds no re-bin, so its launches are the best case; the steady
+    # windows hold the flow's re-bins and the spread-out fluid.  The timed window's figure stays on the
+    # line as roofline.first_window.
+    roof = first_roof
+    if steady is not None and all(steady_kernels[k]["launches"] for k in steady_kernels):
+        roof, steady_per_kernel = roofline_of(steady_kernels, n, cells)
+        roof["window"] = "steady: %d steps after the timed window, every %d-th step sampled" % (steady_steps, args.timing_stride)
+        roof["first_window"] = {k: first_roof[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}
+        steady["kernels"] = steady_per_kernel
+    else:
+        roof["window"] = "timed"
     rebin_in_window = bool(timings["rebin"].get("performed"))
     if "p2g" in per_kernel and timings["rebin"].get("performed_ms") is not None:
-        # P2G with the particle sort included.  From the steady windows when they ran (the timed window
-        # may be too short to hold a re-bin); otherwise from the timed window.
+        # P2G with the particle sort included.  A re-bin rides on the step's own launches (the mass pass
+        # counts, the momentum pass and g2p store to the new slots), so its cost is inside the p2g and
+        # g2p averages of the window it happened in; what the device clocks separately is only the one
+        # workgroup that scans the tile counts ("scan_ms").  From the steady windows when they ran (the
+        # timed window may hold no re-bin); otherwise from the timed window.
         if steady is not None and all(steady_kernels[k]["launches"] for k in ("p2g1", "p2g2")):
             p2g_ms = sum(steady_kernels[k]["ms"] / steady_kernels[k]["launches"] for k in ("p2g1", "p2g2"))
             per_kernel["p2g_with_sort"] = dict(with_sort(p2g_ms, steady["rebin_ms_per_step"], n, cells),
@@ -336,6 +356,7 @@ def run_single(args):
     step_bytes = 212 * n + 112 * cells
     line = {
         "metric": "particle-substeps/sec", "value": n * args.steps / elapsed, "unit": "particle-substeps/s",
+        "value_steady": steady["value"] if steady is not None else None,
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+i32-fixed-point",
         "data": "synthetic",
@@ -356,7 +377,7 @@ def run_single(args):
         # the device's own clock brackets every re-bin it performs (all steps, not only the sampled ones)
         "rebin_in_window": rebin_in_window,
         "steady": steady,
-        "rebin": {"performed": rebin.get("performed"), "performed_ms": round(rebin.get("performed_ms", 0.0), 3),
+        "rebin": {"performed": rebin.get("performed"), "scan_ms": round(rebin.get("performed_ms", 0.0), 3),
                   "ms_per_step": round(rebin.get("performed_ms", 0.0) / args.steps, 4),
                   "timed_steps": rebin["launches"],
                   "avg_ms_per_timed_step": round(rebin["ms"] / rebin["launches"], 4) if rebin["launches"] else None},
@@ -365,7 +386,7 @@ def run_single(args):
         values = [line["value"]] + extra_rounds
         line["rounds"] = {"values": [round(v, 1) for v in values], "median": round(float(np.median(values)), 1),
                           "min": round(min(values), 1)}
-    if not args.no_cpu_baseline and args.mode == "chaos":
+    if want_cpu:
         line["cpu_baseline"] = cpu_baseline(rec, n, grid, uniforms, args.cpu_steps)
     return line
 
@@ -396,7 +417,7 @@ def run_distributed(args):
     import torch
     import torch.distributed as dist
     from flow_amd import _lib
-    from flow_amd.slab import SlabSimulation, balanced_plane_starts
+    from flow_amd.slab import SlabSimulation, plane_starts_from_histogram
 
     single = args.one_slab and "WORLD_SIZE" not in os.environ
     if single:
@@ -430,15 +451,18 @@ def run_distributed(args):
     uniforms = scene_uniforms(n_total, cells, args.scene, args.noise)
     algo = {"tiled": _lib.ALGO_TILED, "tiled_unfused": _lib.ALGO_TILED_UNFUSED, "scatter": _lib.ALGO_SCATTER}[args.algorithm]
 
-    # Every rank generates the id range [rank*n_per, (rank+1)*n_per) of the global scene; the
-    # slab boundaries are chosen so that every slab starts with about the same particle count.
-    mine = make_particles(args.scene, n_per, grid, seed, first_id=rank * n_per)
-    ids = np.arange(rank * n_per, (rank + 1) * n_per, dtype=np.int32)
-    starts = balanced_plane_starts(mine[:, 0], grid[0], world, dist)
-    sim = SlabSimulation(grid, starts, rank, world, max_particles=int(n_per * 2.5), device=local_rank,
-                         algorithm=algo, rebin_interval=args.rebin_interval, dist=dist,
+    # The slab boundaries are cut so that every slab starts with about the same particle count, from the
+    # per-plane histogram of the whole scene (computed on the device straight from the generator: the same
+    # on every rank, so no exchange); then every rank generates the scene on its device and keeps the
+    # particles of its own planes.
+    kind = _lib.SCENE_ELLIPSOID if args.scene == "ellipsoid" else _lib.SCENE_DAM_BREAK
+    hist = _lib.scene_plane_histogram(kind, n_total, grid, seed=seed, fill=0.25, device=local_rank)
+    starts = plane_starts_from_histogram(hist, world)
+    share = int(hist[starts[rank]:starts[rank + 1]].sum())
+    sim = SlabSimulation(grid, starts, rank, world, max_particles=max(int(n_per * 2.5), share + share // 4),
+                         device=local_rank, algorithm=algo, rebin_interval=args.rebin_interval, dist=dist,
                          torch_device=torch.device("cuda", local_rank))
-    sim.scatter_initial_particles(mine, ids)
+    sim.generate_initial_particles(kind, n_total, seed=seed, fill=0.25)
     sim.set_uniforms(**uniforms)
     for _ in range(args.warmup):
         sim.step()

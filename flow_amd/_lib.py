@@ -48,9 +48,10 @@ EXPORTS = (
     "flowmpm_halo_add", "flowmpm_find_leavers", "flowmpm_pack_leavers", "flowmpm_grid_sums",
     "flowmpm_set_domain_particles", "flowmpm_get_allocation_count",
     "flowmpm_download_field_static", "flowmpm_generate_particles", "flowmpm_plane_histogram",
-    "flowmpm_stencil_mass_sum", "flowmpm_abi_sizes",
+    "flowmpm_stencil_mass_sum", "flowmpm_abi_sizes", "flowmpm_scene_plane_histogram", "flowmpm_set_option",
 )
 SCENE_ELLIPSOID, SCENE_DAM_BREAK = 0, 1
+OPTION_RIDE_REBINS, OPTION_DRIFT_DIVISOR, OPTION_CHUNK, OPTION_SPARSE_TILE = range(4)
 
 
 class Config(ctypes.Structure):
@@ -179,6 +180,8 @@ def load():
         "flowmpm_plane_histogram": ([vp, i64p, i32], ctypes.c_int),
         "flowmpm_stencil_mass_sum": ([vp, i64p], ctypes.c_int),
         "flowmpm_abi_sizes": ([i64p], ctypes.c_int),
+        "flowmpm_set_option": ([vp, i32, i64], ctypes.c_int),
+        "flowmpm_scene_plane_histogram": ([i32, i32, u32, i64, i64, ip, ctypes.c_double, i64p], ctypes.c_int),
     }
     for name, (argtypes, restype) in protos.items():
         fn = getattr(L, name)
@@ -199,3 +202,14 @@ def check(handle, code):
     if code != OK:
         msg = load().flowmpm_last_error(handle)
         raise FlowMpmError(code, msg.decode() if msg else "")
+
+
+def scene_plane_histogram(scene, count, grid, seed=0xF10E5EED, first_id=0, fill=0.25, device=0):
+    """Particles per x-plane of a generated scene (flowmpm_scene_plane_histogram), int64[grid[0]]."""
+    import numpy as np
+    g = (ctypes.c_int32 * 3)(*[int(x) for x in grid])
+    out = np.zeros(int(grid[0]), dtype=np.int64)
+    check(None, load().flowmpm_scene_plane_histogram(int(device), int(scene), int(seed) & 0xFFFFFFFF, int(first_id),
+                                                     int(count), g, float(fill),
+                                                     out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+    return out

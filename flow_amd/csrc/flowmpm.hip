@@ -83,7 +83,10 @@ struct flowmpm_sim {
     long long domain_particles = 0;   // slab handles: uniforms.numParticles of the whole domain
     long long uploaded = 0;      // records given to upload (single GPU)
     mpm::StoreSel store{};       // tiled: two stores, re-binning gathers from one into the other
-    int drift_divisor = 256;      // re-bin when (particles outside their arena) * divisor > particles
+    // re-bin when (particles outside their arena) * divisor > particles: drift_divisor for a re-bin that
+    // rides on flowmpm_step (cheap, so it starts early), drift_divisor_standalone for the two-launch form
+    // (stage-by-stage hosts, slab handles)
+    int drift_divisor = 256, drift_divisor_standalone = 256;
     // flowmpm_step of a single-domain handle on the two-pass tiled algorithm lets a re-bin ride on the
     // step's own stores (mpm::RebinCtl::riding) instead of moving every record once more
     // 2: the step's mass pass also counts the tiles; 1: a counting launch of its own; 0: off, the
@@ -488,8 +491,9 @@ int stage_rebin_if_needed(flowmpm_sim *s, bool ride)
     int rc = timing_events(s, FLOWMPM_TIMING_REBIN, &t);
     if (rc) return rc;
     std::string msg;
-    if (mpm::rebin_if_due(T, s->store, s->live, s->params, s->cfg.rebin_interval, s->drift_divisor, s->stream,
-                          t.start, t.stop, &msg, ride ? s->ride_rebins : 0))
+    const int form = ride ? s->ride_rebins : 0;
+    if (mpm::rebin_if_due(T, s->store, s->live, s->params, s->cfg.rebin_interval,
+                          form ? s->drift_divisor : s->drift_divisor_standalone, s->stream, t.start, t.stop, &msg, form))
         return fail(s, FLOWMPM_ERR_HIP, "rebin: " + msg);
     return FLOWMPM_OK;
 }
@@ -718,17 +722,14 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
             // A slab takes in arrivals every step, all of them outside the binning until the next re-bin:
             // it pays to carry more of them for longer (measured on slabs of the 8-slab decomposition
             // of 2^27 particles: 256 -> 2.57, 96 -> 2.44, 48 -> 2.34, 24 -> 2.35, 12 -> 2.36 ms per step).
-            if (s->slab) s->drift_divisor = 48;
+            if (s->slab) s->drift_divisor = s->drift_divisor_standalone = 48;
             s->ride_rebins = (!s->slab && c.algorithm == FLOWMPM_ALGO_TILED) ? 2 : 0;
-            if (const char *env = getenv("FLOWMPM_RIDE_REBINS"))
-                s->ride_rebins = s->ride_rebins ? std::min(2, std::max(0, atoi(env))) : 0;
-            // A riding re-bin costs half of a standalone one, and the step it rides on still runs on the old
+            // A riding re-bin costs a fraction of a standalone one, and the step it rides on still runs on the old
             // binning: it pays to start it earlier (steady state of the benchmark scene, noise uniform 0 / 1:
             // divisor 256 -> 10.17 / 7.78e9 per second, 512 -> 10.24 / 7.98, 1024 -> 10.22 / 7.98, 2048 -> 10.28 / 8.04).
             // With the count in the mass pass and the constant columns in the momentum pass (0.30 ms per re-bin):
             // 1024 -> 10.22 / 8.38, 4096 -> 10.31 / 8.21, 8192 -> 10.35 / 8.45, 16384 -> 10.37 / 8.48.
             if (s->ride_rebins) s->drift_divisor = 8192;
-            if (const char *env = getenv("FLOWMPM_DRIFT_DIVISOR")) s->drift_divisor = atoi(env);
             HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->dirty), (size_t)s->tiled.n_tiles * sizeof(int)));
             HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
         }
@@ -794,20 +795,14 @@ int flowmpm_upload_particles(flowmpm_sim *s, const float *aos, const int32_t *id
     return FLOWMPM_OK;
 }
 
-// The host loop of init() (SIM:114-129) on the device; see kernels_scene.h.
-int flowmpm_generate_particles(flowmpm_sim *s, int32_t scene, uint32_t seed, int64_t first_id, int64_t count,
-                               double fill, int64_t *stored)
+// Checks the arguments of a scene and fills the part of its description that does not depend on a handle.
+static int scene_spec(flowmpm_sim *s, int32_t scene, uint32_t seed, int64_t first_id, int64_t count, double fill,
+                      int gx, int gy, int gz, mpm::SceneSpec *out)
 {
-    CHECK_SIM(s);
-    if (stored) *stored = 0;
     if (scene != FLOWMPM_SCENE_ELLIPSOID && scene != FLOWMPM_SCENE_DAM_BREAK)
         return fail(s, FLOWMPM_ERR_INVALID, "unknown scene");
     if (count < 0 || first_id < 0 || first_id + count > 2147483647LL)
         return fail(s, FLOWMPM_ERR_INVALID, "particle ids must fit 31 bits");
-    if (!s->slab && first_id != 0)
-        return fail(s, FLOWMPM_ERR_INVALID, "a single-domain handle holds the ids 0 .. count - 1");
-    if (!s->slab && count > s->cfg.max_particles)
-        return fail(s, FLOWMPM_ERR_CAPACITY, "more particles than max_particles");
     if (scene == FLOWMPM_SCENE_DAM_BREAK && !(fill > 0.0 && fill <= 1.0))
         return fail(s, FLOWMPM_ERR_INVALID, "the dam-break column needs 0 < fill <= 1");
     // SIM:90-112: the palette as hex strings, converted as the reference does (parseInt / 255)
@@ -820,10 +815,27 @@ int flowmpm_generate_particles(flowmpm_sim *s, int32_t scene, uint32_t seed, int
     sp.seed = seed;
     sp.first_id = first_id;
     sp.count = count;
-    sp.gx = s->cfg.grid_x; sp.gy = s->cfg.grid_y; sp.gz = s->cfg.grid_z;
+    sp.gx = gx; sp.gy = gy; sp.gz = gz;
     sp.fill = fill;
     for (int c = 0; c < 13; c++)
         for (int k = 0; k < 3; k++) sp.palette[c][k] = (float)((double)palette[c][k] / 255.0);
+    *out = sp;
+    return FLOWMPM_OK;
+}
+
+// The host loop of init() (SIM:114-129) on the device; see kernels_scene.h.
+int flowmpm_generate_particles(flowmpm_sim *s, int32_t scene, uint32_t seed, int64_t first_id, int64_t count,
+                               double fill, int64_t *stored)
+{
+    CHECK_SIM(s);
+    if (stored) *stored = 0;
+    mpm::SceneSpec sp{};
+    int rc0 = scene_spec(s, scene, seed, first_id, count, fill, s->cfg.grid_x, s->cfg.grid_y, s->cfg.grid_z, &sp);
+    if (rc0) return rc0;
+    if (!s->slab && first_id != 0)
+        return fail(s, FLOWMPM_ERR_INVALID, "a single-domain handle holds the ids 0 .. count - 1");
+    if (!s->slab && count > s->cfg.max_particles)
+        return fail(s, FLOWMPM_ERR_CAPACITY, "more particles than max_particles");
     sp.keep_lo = s->cfg.slab_x0;
     sp.keep_hi = s->cfg.slab_x0 + s->cfg.slab_nx;
     HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -887,6 +899,31 @@ int flowmpm_plane_histogram(flowmpm_sim *s, int64_t *out, int32_t planes)
     return copy_out_and_wait(s, out, stage, (size_t)planes * sizeof(int64_t), "plane_histogram");
 }
 
+int flowmpm_scene_plane_histogram(int32_t device, int32_t scene, uint32_t seed, int64_t first_id, int64_t count,
+                                  const int32_t grid[3], double fill, int64_t *out)
+{
+    if (!grid || !out) return fail(nullptr, FLOWMPM_ERR_INVALID, "null argument");
+    if (grid[0] < 6 || grid[1] < 6 || grid[2] < 6) return fail(nullptr, FLOWMPM_ERR_INVALID, "grid must be at least 6 cells on every axis");
+    if (grid[0] > mpm::kHistPlanes) return fail(nullptr, FLOWMPM_ERR_UNSUPPORTED, "plane histogram: grid_x above 8192");
+    mpm::SceneSpec sp{};
+    int rc = scene_spec(nullptr, scene, seed, first_id, count, fill, grid[0], grid[1], grid[2], &sp);
+    if (rc) return rc;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    const size_t bytes = (size_t)grid[0] * sizeof(unsigned long long);
+    unsigned long long *d = nullptr;
+    HIP_TRY(nullptr, hipMalloc(reinterpret_cast<void **>(&d), bytes));
+    hipError_t e = hipMemset(d, 0, bytes);
+    if (e == hipSuccess && count > 0) {
+        hipLaunchKernelGGL(mpm::scene_histogram_kernel, dim3((unsigned)std::min<long long>(blocks_for(count, 256), 2048)),
+                           dim3(256), 0, nullptr, sp, (int)grid[0], d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(nullptr, FLOWMPM_ERR_HIP, std::string("scene_plane_histogram: ") + hipGetErrorString(e));
+    return FLOWMPM_OK;
+}
+
 int flowmpm_stencil_mass_sum(flowmpm_sim *s, int64_t *out)
 {
     CHECK_SIM(s);
@@ -942,6 +979,36 @@ int flowmpm_set_uniforms(flowmpm_sim *s, const flowmpm_uniforms *u)
     s->uniforms = *u;
     refresh_params(s);
     return FLOWMPM_OK;
+}
+
+int flowmpm_set_option(flowmpm_sim *s, int32_t option, int64_t value)
+{
+    if (!s) return fail(nullptr, FLOWMPM_ERR_INVALID, "null handle");
+    if (!is_tiled(s)) return fail(s, FLOWMPM_ERR_INVALID, "the options belong to the tiled algorithms");
+    switch (option) {
+    case FLOWMPM_OPTION_RIDE_REBINS:
+        if (value < 0 || value > 2) return fail(s, FLOWMPM_ERR_INVALID, "ride form must be 0, 1 or 2");
+        if (value != 0 && (s->slab || s->cfg.algorithm != FLOWMPM_ALGO_TILED))
+            return fail(s, FLOWMPM_ERR_UNSUPPORTED, "re-bins ride only on flowmpm_step of a single-domain two-pass handle");
+        s->ride_rebins = (int)value;
+        return FLOWMPM_OK;
+    case FLOWMPM_OPTION_DRIFT_DIVISOR:
+        if (value < 0 || value > (1 << 30)) return fail(s, FLOWMPM_ERR_INVALID, "drift divisor out of range");
+        s->drift_divisor = s->drift_divisor_standalone = (int)value;
+        return FLOWMPM_OK;
+    case FLOWMPM_OPTION_CHUNK:
+        if (value < 1 || value > (1 << 30)) return fail(s, FLOWMPM_ERR_INVALID, "work-item size out of range");
+        s->tiled.chunk_wanted = (int)value;
+        s->tiled.valid = false;          // takes effect with a forced re-bin, which the next step performs
+        return FLOWMPM_OK;
+    case FLOWMPM_OPTION_SPARSE_TILE:
+        if (value < 0 || value > (1 << 30)) return fail(s, FLOWMPM_ERR_INVALID, "sparse-tile bound out of range");
+        s->tiled.sparse_wanted = (int)value;
+        s->tiled.valid = false;
+        return FLOWMPM_OK;
+    default:
+        return fail(s, FLOWMPM_ERR_INVALID, "unknown option");
+    }
 }
 
 int flowmpm_set_mode_uniforms(flowmpm_sim *s, const flowmpm_mode_uniforms *m)

@@ -43,6 +43,30 @@ __device__ __forceinline__ double scene_uniform01(unsigned seed, unsigned index,
     return (double)h / 4294967296.0;
 }
 
+// Position of particle `id`, rounded to binary32 once.
+__device__ __forceinline__ void scene_position(const SceneSpec &sp, unsigned id, float *px, float *py, float *pz)
+{
+    double x, y, z;
+    if (sp.kind == kSceneEllipsoid) {
+        double ux = 0.0, uy = 0.0, uz = 0.0;
+        for (unsigned attempt = 0; attempt < 4096u; attempt++) {
+            const double cx = scene_uniform01(sp.seed, id, 3u * attempt + 0u) * 2.0 - 1.0;
+            const double cy = scene_uniform01(sp.seed, id, 3u * attempt + 1u) * 2.0 - 1.0;
+            const double cz = scene_uniform01(sp.seed, id, 3u * attempt + 2u) * 2.0 - 1.0;
+            if (sqrt((cx * cx + cy * cy) + cz * cz) <= 1.0) { ux = cx; uy = cy; uz = cz; break; }
+        }
+        x = (ux * 0.8 + 1.0) / 2.0 * sp.gx;
+        y = (uy * 0.8 + 1.0) / 2.0 * sp.gy;
+        z = (uz * 0.8 + 1.0) / 2.0 * sp.gz;
+    } else {
+        const double hx = fmax(sp.fill * sp.gx, 4.0), hy = sp.gy - 3.0, hz = sp.gz - 3.0;
+        x = 3.0 + scene_uniform01(sp.seed, id, 0u) * (hx - 3.0);
+        y = 3.0 + scene_uniform01(sp.seed, id, 1u) * (hy - 3.0);
+        z = 3.0 + scene_uniform01(sp.seed, id, 2u) * (hz - 3.0);
+    }
+    *px = (float)x; *py = (float)y; *pz = (float)z;
+}
+
 // counter == nullptr: particle first_id + i goes to slot first_slot + i.  Otherwise the kept particles
 // are appended from first_slot on in no particular order (one atomic per wave), and *counter ends up as
 // their number -- also when they do not all fit below `capacity` (the host checks).
@@ -57,25 +81,8 @@ generate_scene_kernel(SceneSpec sp, StoreSel ss, long long first_slot, long long
         const long long i = i0 + threadIdx.x;
         const bool live = i < sp.count;
         const unsigned id = (unsigned)(sp.first_id + (live ? i : 0));
-        double x, y, z;
-        if (sp.kind == kSceneEllipsoid) {
-            double ux = 0.0, uy = 0.0, uz = 0.0;
-            for (unsigned attempt = 0; attempt < 4096u; attempt++) {
-                const double cx = scene_uniform01(sp.seed, id, 3u * attempt + 0u) * 2.0 - 1.0;
-                const double cy = scene_uniform01(sp.seed, id, 3u * attempt + 1u) * 2.0 - 1.0;
-                const double cz = scene_uniform01(sp.seed, id, 3u * attempt + 2u) * 2.0 - 1.0;
-                if (sqrt((cx * cx + cy * cy) + cz * cz) <= 1.0) { ux = cx; uy = cy; uz = cz; break; }
-            }
-            x = (ux * 0.8 + 1.0) / 2.0 * sp.gx;
-            y = (uy * 0.8 + 1.0) / 2.0 * sp.gy;
-            z = (uz * 0.8 + 1.0) / 2.0 * sp.gz;
-        } else {
-            const double hx = fmax(sp.fill * sp.gx, 4.0), hy = sp.gy - 3.0, hz = sp.gz - 3.0;
-            x = 3.0 + scene_uniform01(sp.seed, id, 0u) * (hx - 3.0);
-            y = 3.0 + scene_uniform01(sp.seed, id, 1u) * (hy - 3.0);
-            z = 3.0 + scene_uniform01(sp.seed, id, 2u) * (hz - 3.0);
-        }
-        const float px = (float)x, py = (float)y, pz = (float)z;
+        float px, py, pz;
+        scene_position(sp, id, &px, &py, &pz);
         const float mass = (float)(1.0 - scene_uniform01(sp.seed ^ 0x5BD1E995u, id, 0u) * 0.002);
         long long slot = first_slot + i;
         bool keep = live;
@@ -117,6 +124,25 @@ plane_histogram_kernel(StoreSel ss, long long n, int planes, unsigned long long 
     for (long long j = begin + threadIdx.x; j < end; j += blockDim.x) {
         const int ix = min(max(f32_to_i32(st.slot(kPosX)[(unsigned)j]), 0), planes - 1);
         atomicAdd(&local[ix], 1);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < planes; p += blockDim.x)
+        if (local[p]) atomicAdd(out + p, (unsigned long long)local[p]);
+}
+
+// The same histogram of a scene's particles, straight from the generator (no store): what a host cuts
+// balanced slabs from before any slab handle exists.
+__global__ void __launch_bounds__(256)
+scene_histogram_kernel(SceneSpec sp, int planes, unsigned long long *__restrict__ out)
+{
+    __shared__ int local[kHistPlanes];
+    for (int p = threadIdx.x; p < planes; p += blockDim.x) local[p] = 0;
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < sp.count; i += stride) {
+        float px, py, pz;
+        scene_position(sp, (unsigned)(sp.first_id + i), &px, &py, &pz);
+        atomicAdd(&local[min(max(f32_to_i32(px), 0), planes - 1)], 1);
     }
     __syncthreads();
     for (int p = threadIdx.x; p < planes; p += blockDim.x)

@@ -58,23 +58,6 @@ constexpr int kLargeItem = 1024;     // particles; see scan_tiles
 #ifndef FLOWMPM_G2P_WAVES
 #define FLOWMPM_G2P_WAVES 1
 #endif
-// Timing experiments only (WRONG results; tools/ablate.sh): bit 0 g2p's gather without its LDS reads,
-// bit 1 g2p without the noise field, bit 2 g2p without its stores, bit 3 the momentum pass without its LDS
-// atomics, bit 4 the momentum pass without the mass reads of its density sum, bit 5 g2p with half of its
-// stores, bit 6 every arena access free of bank conflicts, bits 7 / 8 / 9 the mass pass without its LDS
-// atomics / without the global atomics of its flush / without marking the tiles it touched.
-#ifndef FLOWMPM_ABLATE
-#define FLOWMPM_ABLATE 0
-#endif
-// Experiment (tools/exp_g2p_fma.py): g2p's affine sums B += (w g) (x) dist as fused multiply-adds.  The
-// fixed-point grid of a step does not depend on g2p, and the stated tolerance for particle state is 1e-5
-// relative, but the bits are no longer the reference's: never the default.
-#ifndef FLOWMPM_G2P_FMA
-#define FLOWMPM_G2P_FMA 0
-#endif
-#ifndef FLOWMPM_EXP_NO_SETUP
-#define FLOWMPM_EXP_NO_SETUP 0
-#endif
 
 // Diagnostic build only (-DFLOWMPM_STAMPS=1, tools/clock_stamps.py): every workgroup of the momentum
 // pass and of g2p stamps the shader clock (s_memtime, one tick per shader cycle) and the constant
@@ -162,8 +145,10 @@ struct alignas(32) RebinCtl {
     // `dense` on.  dense_next: of the binning a re-bin in flight is building.
     int dense, dense_next;
     int rebins;      // re-bins performed since the counter was last cleared
-    // Device time those re-bins took, in ticks of the constant-rate wall clock (from the first
-    // workgroup of the first launch to the commit in the second), and the start of the one in flight.
+    // Device time of the re-bins' OWN launches, in ticks of the constant-rate wall clock: for the standalone
+    // form from the first workgroup of the count launch to the commit in the scatter launch; for a riding
+    // re-bin only the launch that scans the tile counts (the rest of its work is inside the step's mass
+    // pass, momentum pass and g2p and is timed with them).  And the start of the one in flight.
     unsigned long long busy_ticks;
     unsigned long long stragglers;   // particles the g2p stages since then handed to the follow-up kernel
     unsigned long long t_start;      // ~0 when no re-bin is in flight
@@ -198,6 +183,7 @@ struct TiledState {
     int *straggler_list = nullptr;
     int chunk = kChunkMax;       // particles per work item of the current binning (choose_chunk)
     int sparse = 0;              // tiles with fewer particles get no work item (choose_sparse)
+    int chunk_wanted = kChunkMax, sparse_wanted = 0;      // what the next forced re-bin takes them from
     // A riding re-bin whose tiles the coming mass pass counts: the launch that builds the next item set
     // follows that pass (launch_p2g_mass_tiled), timed with these events.
     bool scan_after_mass = false;
@@ -737,10 +723,6 @@ __device__ __forceinline__ bool stencil_in_arena(const Stencil &s, const Arena &
 {
     const int bx = s.cx - A.ox, by = s.cy - A.oy, bz = s.cz - A.oz;   // arena coords of the stencil base
     *abase = arena_index(bx, by, bz);
-#if FLOWMPM_ABLATE & 64      // timing experiment (wrong results): every 32 lanes hold 32 different banks
-    *abase = (*abase & ~31) | (int)(threadIdx.x & 31);
-    if (*abase > kArenaCells - 1 - arena_index(2, 2, 2)) *abase -= 32;
-#endif
     return (unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
            (unsigned)bz <= (unsigned)(kAZ - 3);
 }
@@ -905,11 +887,7 @@ __device__ __forceinline__ void p2g_mass_particle(const Stencil &s, int *lds, in
             for (int gz = 0; gz < 3; gz++) {
                 int em = encode_fixed(wxy * s.wz[gz]);
                 if (INSIDE) {
-#if FLOWMPM_ABLATE & 128
-                    if (em == 0x7ABCDEF1) lds[abase] = 1;
-#else
                     atomicAdd(&lds[abase + arena_index(gx, gy, gz)], em);
-#endif
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     if (c >= 0) atomicAdd(g.mass + c, em);
@@ -950,7 +928,10 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
                 w.rank[j] = kRankNotMine;
             } else {
                 // tile of floor(position) = s.c + 1; inside the arena it is this tile or one next to it
-                const int kx = (s.cx + 1 - P.x_off) / kTX, ky = (s.cy + 1) / kTY, kz = (s.cz + 1) / kTZ;
+                // (clamped to the grid like tile_of: a position on the top face of a grid whose extent is a
+                // multiple of the tile size would otherwise name a tile that does not exist)
+                const int kx = min((s.cx + 1 - P.x_off) / kTX, w.td.tiles_x - 1), ky = min((s.cy + 1) / kTY, w.td.tiles_y - 1),
+                          kz = min((s.cz + 1) / kTZ, w.td.tiles_z - 1);
                 const int nb = ((kx - tx0 + 1) * 3 + (ky - ty0 + 1)) * 3 + (kz - tz0 + 1);
                 w.key[j] = (kx * w.td.tiles_y + ky) * w.td.tiles_z + kz;
                 w.rank[j] = (nb << kRankNbShift) | atomicAdd(&nb_count[nb], 1);
@@ -970,15 +951,9 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         int v = lds[a];
         if (v == 0) continue;
         long long c = arena_cell_to_grid(a, A, P);
-#if FLOWMPM_ABLATE & 256
-        if (c == 0x7ABCDEF1) g.mass[0] = v;
-#else
         if (c >= 0) atomicAdd(g.mass + c, v);
-#endif
     }
-#if !(FLOWMPM_ABLATE & 512)
     mark_dirty_tiles(touched, item.x, w.td, g);
-#endif
     if (!counting) return;                                   // uniform
     // this workgroup's share of the 27 tile counters, then the ranks become ranks inside the tile
     if (threadIdx.x < 27 && nb_count[threadIdx.x] > 0) {
@@ -1010,11 +985,7 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
                 float weight = wxy * s.wz[gz];
                 float m;
                 if (INSIDE) {
-#if FLOWMPM_ABLATE & 16
-                    m = s.wx[gx];
-#else
                     m = mass_f[abase + arena_index(gx, gy, gz)];
-#endif
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     m = decode_fixed((c >= 0) ? g.mass[c] : 0);
@@ -1048,13 +1019,9 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
                 ez = add_wrap(ez, encode_fixed((a02 * dx + a12 * dy) + a22 * dz));
                 if (INSIDE) {
                     int a = abase + arena_index(gx, gy, gz);
-#if FLOWMPM_ABLATE & 8
-                    if (ex == 0x7ABCDEF1 && ey == 0x7ABCDEF2 && ez == a) lds[a] = 1;      // keeps the arithmetic alive
-#else
                     atomicAdd(&lds[0 * kArenaPad + a], ex);
                     atomicAdd(&lds[1 * kArenaPad + a], ey);
                     atomicAdd(&lds[2 * kArenaPad + a], ez);
-#endif
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     if (c >= 0) {
@@ -1067,104 +1034,8 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
         }
 }
 
-// Experiment (-DFLOWMPM_WAVE_REDUCE=1, tools/exp_wave_reduce.py): a segmented reduction over the wave in
-// front of the LDS atomics.  Lanes that hold particles of the same cell add to the same 27 x 3 words; with
-// the particles ordered by cell inside a tile such lanes are neighbours, and their already ENCODED words
-// (integers: regrouping is exact) are summed with DPP row shifts first, so that only the first lane of a
-// run issues the atomic.  A run ends at a change of cell and at every 16th lane (a DPP row).
-#ifndef FLOWMPM_WAVE_REDUCE
-#define FLOWMPM_WAVE_REDUCE 0
-#endif
-// Which kernel carries the columns no stage writes (mass, colour, id) to the particle's new slot while
-// a re-bin rides on the step: 1 the momentum pass (bound by LDS and VALU, with memory bandwidth to
-// spare), 0 g2p.
-#ifndef FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
-#define FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM 1
-#endif
-#if FLOWMPM_WAVE_REDUCE
-struct SegMasks { unsigned m[4]; bool head; };
-
-// row_shl:D -- lane i reads lane i + D of its row of 16, 0 past the end of the row
-template <int D>
-__device__ __forceinline__ int row_from_above(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + D, 0xF, 0xF, true); }
-
-// seg: the same positive number on lanes of one cell, a distinct negative one on lanes that take no part
-__device__ __forceinline__ SegMasks seg_masks(int seg)
-{
-    SegMasks r;
-    // m[k]: lanes i .. i + 2^k all hold the same cell (an equal cell further up behind a different one
-    // belongs to another run, which has a first lane of its own)
-    r.m[0] = row_from_above<1>(seg) == seg ? ~0u : 0u;
-    r.m[1] = r.m[0] & (unsigned)row_from_above<1>((int)r.m[0]);
-    r.m[2] = r.m[1] & (unsigned)row_from_above<2>((int)r.m[1]);
-    r.m[3] = r.m[2] & (unsigned)row_from_above<4>((int)r.m[2]);
-    r.head = __builtin_amdgcn_update_dpp(0, seg, 0x111, 0xF, 0xF, true) != seg;      // row_shr:1
-    return r;
-}
-
-__device__ __forceinline__ int seg_reduce(int v, const SegMasks &sm)
-{
-    v = add_wrap(v, (int)((unsigned)row_from_above<1>(v) & sm.m[0]));
-    v = add_wrap(v, (int)((unsigned)row_from_above<2>(v) & sm.m[1]));
-    v = add_wrap(v, (int)((unsigned)row_from_above<4>(v) & sm.m[2]));
-    v = add_wrap(v, (int)((unsigned)row_from_above<8>(v) & sm.m[3]));
-    return v;
-}
-
-// p2g_momentum_particle<true> for every lane of the wave at once; `inside` lanes are the ones that count
-__device__ __forceinline__ void p2g_momentum_particle_reduced(const Stencil &s, float vx, float vy, float vz,
-                                                              const float C[9], const float *dens_slot,
-                                                              float *dens_out, int *lds, const float *mass_f,
-                                                              int abase, bool inside, const SegMasks &sm,
-                                                              const Params &P)
-{
-    float density = 0.0f;
-#pragma unroll
-    for (int gx = 0; gx < 3; gx++)
-#pragma unroll
-        for (int gy = 0; gy < 3; gy++) {
-            float wxy = s.wx[gx] * s.wy[gy];
-#pragma unroll
-            for (int gz = 0; gz < 3; gz++)
-                density = density + mass_f[abase + arena_index(gx, gy, gz)] * (wxy * s.wz[gz]);
-        }
-    if (inside) *dens_out = *dens_slot * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
-    Eq16 e = p2g2_stress(density, C, P);
-    const bool issue = inside && sm.head;
-#pragma unroll
-    for (int gx = 0; gx < 3; gx++)
-#pragma unroll
-        for (int gy = 0; gy < 3; gy++) {
-            float wxy = s.wx[gx] * s.wy[gy];
-#pragma unroll
-            for (int gz = 0; gz < 3; gz++) {
-                float weight = wxy * s.wz[gz];
-                float dx = s.dx[gx], dy = s.dy[gy], dz = s.dz[gz];
-                float qx = (C[0] * dx + C[3] * dy) + C[6] * dz;
-                float qy = (C[1] * dx + C[4] * dy) + C[7] * dz;
-                float qz = (C[2] * dx + C[5] * dy) + C[8] * dz;
-                int ex = encode_fixed(weight * (vx + qx));
-                int ey = encode_fixed(weight * (vy + qy));
-                int ez = encode_fixed(weight * (vz + qz));
-                float a00 = e.m00 * weight, a11 = e.m11 * weight, a22 = e.m22 * weight;
-                float a01 = e.m01 * weight, a02 = e.m02 * weight, a12 = e.m12 * weight;
-                ex = add_wrap(ex, encode_fixed((a00 * dx + a01 * dy) + a02 * dz));
-                ey = add_wrap(ey, encode_fixed((a01 * dx + a11 * dy) + a12 * dz));
-                ez = add_wrap(ez, encode_fixed((a02 * dx + a12 * dy) + a22 * dz));
-                ex = seg_reduce(inside ? ex : 0, sm);
-                ey = seg_reduce(inside ? ey : 0, sm);
-                ez = seg_reduce(inside ? ez : 0, sm);
-                if (issue) {
-                    int a = abase + arena_index(gx, gy, gz);
-                    atomicAdd(&lds[0 * kArenaPad + a], ex);
-                    atomicAdd(&lds[1 * kArenaPad + a], ey);
-                    atomicAdd(&lds[2 * kArenaPad + a], ez);
-                }
-            }
-        }
-}
-#endif
-
+// While a re-bin rides on the step, the momentum pass (bound by LDS and VALU, with memory bandwidth to
+// spare) also carries the columns no stage writes -- mass, colour, id -- to the particle's new slot.
 __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_P2G_WAVES)
 p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
@@ -1184,57 +1055,28 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     // measured here too: no change when it costs no registers, and a wave per SIMD less when it does.)
     for (int i = threadIdx.x; i < 3 * kArenaPad; i += kTiledThreads) lds[i] = 0;
     for (int a = threadIdx.x; a < kArenaCells; a += kTiledThreads) {
-#if FLOWMPM_EXP_NO_SETUP      // timing experiment only (wrong results): what the arena loads cost
-        mass_f[a] = 1.0f;
-#else
         long long c = arena_cell_to_grid(a, A, P);
         mass_f[a] = decode_fixed((c >= 0) ? g.mass[c] : 0);
-#endif
     }
     __syncthreads();
     const Column<float> dens = st.slot(kDensity);
     const Ride ride = ride_of(w, head, st);
     const Column<float> dens_out = ride.dst.slot(kDensity);
-#if !FLOWMPM_WAVE_REDUCE
     float in[15];
     int j = item.y + threadIdx.x;
     if (j < item.z) {
 #pragma unroll
         for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
     }
-#endif
     stamp.begin();
     // Software pipeline: the next particle's 15 loads are issued before this particle's LDS
     // atomics and density store, so an iteration never starts by waiting on memory.
-#if FLOWMPM_WAVE_REDUCE
-    // every lane of the wave takes every trip, so that the row shifts see all 64 lanes
-    for (int j0 = item.y; j0 < item.z; j0 += kTiledThreads) {
-        const int j = j0 + threadIdx.x;
-        const bool live = j < item.z;
-        float in[15];
-#pragma unroll
-        for (int k = 0; k < 15; k++) in[k] = live ? st.slot(kPosX + k)[j] : 2.0f;
-        Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
-        int abase;
-        const bool inside = stencil_in_arena(s, A, &abase) && live;
-        if (live && !inside) add_straggler(sg, sb, j);
-#if FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
-        if (live && ride.on) ride_carry_constants(st, ride.dst, j, ride.slot(j));
-#endif
-        if (!inside) abase = 0;
-        const SegMasks sm = seg_masks(inside ? abase + 1 : -1 - (int)(threadIdx.x & 63));
-        p2g_momentum_particle_reduced(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + (live ? j : item.y),
-                                      dens_out + (live ? ride.slot(j) : 0), lds, mass_f, abase, inside, sm, P);
-    }
-#else
     while (j < item.z) {
         const int jn = j + kTiledThreads;
         Stencil s = make_stencil(in[kPosX], in[kPosY], in[kPosZ]);
         int abase;
         const int d = ride.slot(j);
-#if FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
         if (ride.on) ride_carry_constants(st, ride.dst, j, d);      // stragglers included: every slot of the run
-#endif
         if (stencil_in_arena(s, A, &abase))
             p2g_momentum_particle<true>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + j,
                                         dens_out + d, lds, mass_f, abase, g, P);
@@ -1246,7 +1088,6 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         }
         j = jn;
     }
-#endif
     stamp.end(0);
     straggler_buf_flush(sg, sb);
     __syncthreads();
@@ -1286,11 +1127,7 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                 const float weight = gz == 0 ? w01.x : gz == 1 ? w01.y : w2;
                 float4 f;
                 if (INSIDE) {
-#if FLOWMPM_ABLATE & 1
-                    f = make_float4(s.wx[gx], s.wy[gy], s.wz[gz], 0.0f);
-#else
                     f = grid[abase + arena_index(gx, gy, gz)];
-#endif
                 } else {
                     long long c = local_cell(s.cx + gx, s.cy + gy, s.cz + gz, P);
                     f = (c >= 0) ? cellf[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1298,19 +1135,11 @@ __device__ __forceinline__ void g2p_gather(const Stencil &s, const float4 *grid,
                 const Float2v wvxy = Float2v{f.x, f.y} * weight;
                 const float wvz = f.z * weight;
                 const float dz = s.dz[gz];
-#if FLOWMPM_G2P_FMA      // experiment: the nine affine sums contracted (NOT the reference's bits)
-                B01 = __builtin_elementwise_fma(wvxy, Float2v{dxy.x, dxy.x}, B01);
-                B34 = __builtin_elementwise_fma(wvxy, Float2v{dxy.y, dxy.y}, B34);
-                B67 = __builtin_elementwise_fma(wvxy, Float2v{dz, dz}, B67);
-                B25 = __builtin_elementwise_fma(Float2v{wvz, wvz}, dxy, B25);
-                B8 = __builtin_fmaf(wvz, dz, B8);
-#else
                 B01 = B01 + wvxy * dxy.x;
                 B34 = B34 + wvxy * dxy.y;
                 B67 = B67 + wvxy * dz;
                 B25 = B25 + wvz * dxy;
                 B8 = B8 + wvz * dz;
-#endif
                 vxy = vxy + wvxy;
                 vz = vz + wvz;
             }
@@ -1349,14 +1178,10 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
     for (int q = 0; q < kArenaPerThread; q++) {
         const int a = threadIdx.x + q * kTiledThreads;
         const long long c = a < kArenaCells ? arena_cell_to_grid(a, A, P) : -1;
-#if FLOWMPM_EXP_NO_SETUP
-        arena_raw[q] = make_float4(0.01f, 0.01f, 0.01f, 1.0f);
-#else
         // always a load (of cell 0 for a cell outside the grid), then a select: a load under a branch is
         // waited for at the end of the branch
         const float4 v = cellf[c >= 0 ? c : 0];
         arena_raw[q] = (c >= 0) ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#endif
     }
 
     // Software pipeline: the next particle's loads are issued before this particle's 18 stores
@@ -1413,27 +1238,12 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
                 const int tile = ride.key[j];
                 d = ride.start[tile] + ride.rank[j];
                 An = arena_of_tile(tile, w.td, P);
-#if !FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
-                ride_carry_constants(st, out, j, d);
-#endif
             }
-#if FLOWMPM_ABLATE & 4       // no stores; the values stay alive
-#pragma unroll
-            for (int k = 0; k < 9; k++) asm volatile("" :: "v"(o.C[k]));
-            asm volatile("" :: "v"(o.px), "v"(o.py), "v"(o.pz), "v"(o.vx), "v"(o.vy), "v"(o.vz), "v"(o.dirx), "v"(o.diry), "v"(o.dirz));
-#elif FLOWMPM_ABLATE & 32    // half of the stores
-#pragma unroll
-            for (int k = 0; k < 9; k++) asm volatile("" :: "v"(o.C[k]));
-            out.slot(kPosX)[d] = o.px; out.slot(kPosY)[d] = o.py; out.slot(kPosZ)[d] = o.pz;
-            out.slot(kVelX)[d] = o.vx; out.slot(kVelY)[d] = o.vy; out.slot(kVelZ)[d] = o.vz;
-            out.slot(kDirX)[d] = o.dirx; out.slot(kDirY)[d] = o.diry; out.slot(kDirZ)[d] = o.dirz;
-#else
 #pragma unroll
             for (int k = 0; k < 9; k++) out.slot(kC00 + k)[d] = o.C[k];
             out.slot(kPosX)[d] = o.px; out.slot(kPosY)[d] = o.py; out.slot(kPosZ)[d] = o.pz;
             out.slot(kVelX)[d] = o.vx; out.slot(kVelY)[d] = o.vy; out.slot(kVelZ)[d] = o.vz;
             out.slot(kDirX)[d] = o.dirx; out.slot(kDirY)[d] = o.diry; out.slot(kDirZ)[d] = o.dirz;
-#endif
             const int bx = f32_to_i32(o.px) - 1 - An.ox, by = f32_to_i32(o.py) - 1 - An.oy,
                       bz = f32_to_i32(o.pz) - 1 - An.oz;
             drifted += !((unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
@@ -1551,10 +1361,8 @@ straggler_p2g_team_kernel(TiledWork w, FixedGrid g, Params P)
             const Ride ride = ride_of(w, st);
             const int d = ride.slot(j);
             ride.dst.slot(kDensity)[d] = st.slot(kDensity)[j] * (1.0f - 0.05f) + density * 0.05f;      // SIM:365-366
-#if FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
             // a particle no work item covers: nothing else carries its constant columns to the new slot
             if (ride.on && i >= count) ride_carry_constants(st, ride.dst, j, d);
-#endif
         }
         const Eq16 e = p2g2_stress(density, C, P);
         const float dx = pick3(s.dx, gx), dy = pick3(s.dy, gy), dz = pick3(s.dz, gz);
@@ -1629,9 +1437,6 @@ straggler_g2p_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
             const int tile = ride.key[j];
             d = ride.start[tile] + ride.rank[j];
             const Arena An = arena_of_tile(tile, w.td, P);
-#if !FLOWMPM_RIDE_CONSTANTS_IN_MOMENTUM
-            ride_carry_constants(st, out, j, d);
-#endif
             const int bx = f32_to_i32(o.px) - 1 - An.ox, by = f32_to_i32(o.py) - 1 - An.oy,
                       bz = f32_to_i32(o.pz) - 1 - An.oz;
             drifted += !((unsigned)bx <= (unsigned)(kAX - 3) && (unsigned)by <= (unsigned)(kAY - 3) &&
@@ -1784,32 +1589,19 @@ inline void tiled_free(TiledState &T)
 #endif
 constexpr unsigned kBinBlocks = FLOWMPM_BIN_BLOCKS;
 
-// Work-item size for a binning of n particles.  Measured (profiles/r02_chunk_sweep.txt): splitting a tile
-// over more, smaller work items to fill the chip makes small scenes SLOWER -- every item pays for its
-// arena (zeroing, the mass words, the flush), and that, not idle compute units, is what a small scene
-// spends its time on (2^20 particles / 128^3: 4096 -> 5.51e9/s, 512 -> 4.94, 256 -> 3.85).  So the
-// upper bound is the default; FLOWMPM_CHUNK sets another size (a multiple of the workgroup size) for
-// experiments.
-inline int choose_chunk(long long n)
+// Work-item size of a binning.  Measured (profiles/r02_chunk_sweep.txt): splitting a tile over more,
+// smaller work items to fill the chip makes small scenes SLOWER -- every item pays for its arena (zeroing,
+// the mass words, the flush), and that, not idle compute units, is what a small scene spends its time on
+// (2^20 particles / 128^3: 4096 -> 5.51e9/s, 512 -> 4.94, 256 -> 3.85).  So the upper bound is the
+// default; TiledState::chunk_wanted (flowmpm_set_option) asks for another size, for experiments.
+inline int choose_chunk(const TiledState &T)
 {
-    (void)n;
-    int chunk = kChunkMax;
-    if (const char *env = getenv("FLOWMPM_CHUNK")) chunk = atoi(env);
-    chunk = (chunk + kTiledThreads - 1) / kTiledThreads * kTiledThreads;
+    const int chunk = (T.chunk_wanted + kTiledThreads - 1) / kTiledThreads * kTiledThreads;
     return std::min(kChunkMax, std::max(kChunkMin, chunk));
 }
 
-// Below how many particles a tile gets no work item (RebinCtl::dense).  FLOWMPM_SPARSE_TILE sets another
-// bound; 0 gives every occupied tile its work item.
-#ifndef FLOWMPM_SPARSE_TILE_DEFAULT
-#define FLOWMPM_SPARSE_TILE_DEFAULT 0
-#endif
-inline int choose_sparse()
-{
-    int sparse = FLOWMPM_SPARSE_TILE_DEFAULT;
-    if (const char *env = getenv("FLOWMPM_SPARSE_TILE")) sparse = atoi(env);
-    return std::min(std::max(sparse, 0), kChunkMin);
-}
+// Below how many particles a tile gets no work item (RebinCtl::dense); 0 gives every occupied tile one.
+inline int choose_sparse(const TiledState &T) { return std::min(std::max(T.sparse_wanted, 0), kChunkMin); }
 
 // Enqueues the start-of-step pair of launches (see "binning" above).  When a re-bin is due the
 // first n particles of the current store are grouped by tile into the other store, the work
@@ -1829,8 +1621,8 @@ inline int rebin_if_due(TiledState &T, StoreSel ss, long long n, const Params &P
     const int force = T.valid ? 0 : 1;
     if (force) {
         ride = 0;
-        T.chunk = choose_chunk(n);      // kept until the next forced re-bin: the launch bounds rely on it
-        T.sparse = choose_sparse();
+        T.chunk = choose_chunk(T);      // kept until the next forced re-bin: the launch bounds rely on it
+        T.sparse = choose_sparse(T);
     }
     T.listed = -1;
     if (ride == 2) {

@@ -211,11 +211,7 @@ __device__ __forceinline__ Vec3 g2p_pre_forces(float px, float py, float pz, con
     v.x = v.x - (pn.x * 0.1f) * P.dt;
     v.y = v.y - (pn.y * 0.1f) * P.dt;
     v.z = v.z - (pn.z * 0.1f) * P.dt;
-#if defined(FLOWMPM_ABLATE) && (FLOWMPM_ABLATE & 2)      // timing experiment only: g2p without the noise field
-    Vec3 n = Vec3{px, py, pz};
-#else
     Vec3 n = tri_noise3d(Vec3{px * 0.015f, py * 0.015f, pz * 0.015f}, P.time, 0.11f);
-#endif
     n = normalize3(Vec3{n.x - 0.285f, n.y - 0.285f, n.z - 0.285f});
     n = Vec3{n.x * 0.28f, n.y * 0.28f, n.z * 0.28f};
     v.x = v.x - (n.x * P.noise) * P.dt;

@@ -12,6 +12,7 @@ use directly.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 
@@ -50,6 +51,17 @@ class Handle:
         self.slab = slab
         self._h = ctypes.c_void_p()
         _lib.check(None, self.L.flowmpm_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+        # A/B switches of the measurement tools: the library itself reads no environment variable
+        if algorithm != _lib.ALGO_SCATTER:
+            for name, option in (("FLOWMPM_RIDE_REBINS", _lib.OPTION_RIDE_REBINS),
+                                 ("FLOWMPM_DRIFT_DIVISOR", _lib.OPTION_DRIFT_DIVISOR),
+                                 ("FLOWMPM_CHUNK", _lib.OPTION_CHUNK), ("FLOWMPM_SPARSE_TILE", _lib.OPTION_SPARSE_TILE)):
+                value = os.environ.get(name)
+                if value is None:
+                    continue
+                if option == _lib.OPTION_RIDE_REBINS and (slab or algorithm != _lib.ALGO_TILED):
+                    continue          # such handles never ride
+                self.set_option(option, int(value))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -95,6 +107,10 @@ class Handle:
         out = ctypes.c_int64()
         self._chk(self.L.flowmpm_stencil_mass_sum(self._h, ctypes.byref(out)))
         return out.value
+
+    def set_option(self, option, value):
+        """flowmpm_set_option: tuning of the tiled algorithms (never affects results)."""
+        self._chk(self.L.flowmpm_set_option(self._h, int(option), int(value)))
 
     def set_num_particles(self, n):
         self._chk(self.L.flowmpm_set_num_particles(self._h, int(n)))

@@ -319,6 +319,14 @@ class SlabSimulation:
         self.backend.upload(np.ascontiguousarray(allrec[:, :_lib.PARTICLE_STRIDE]),
                             np.ascontiguousarray(allrec[:, _lib.PARTICLE_STRIDE]).view(np.int32))
 
+    def generate_initial_particles(self, scene, total, seed=0xF10E5EED, fill=0.25):
+        """The whole seeded scene generated on this rank's device, of which the slab keeps the particles
+        of its own planes (flowmpm_generate_particles): no host records, no exchange.  Library backend
+        only.  Returns the number of particles this rank holds."""
+        self._residents = None
+        self.backend.set_domain_particles(int(total))
+        return self.backend.handle.generate_particles(scene, int(total), seed=seed, fill=fill)
+
     def _comm_device(self):
         if self.dist is not None and self.dist.get_backend() == "nccl":
             return self.backend.torch_device

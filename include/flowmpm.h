@@ -253,6 +253,23 @@ int flowmpm_set_uniforms(flowmpm_sim *sim, const flowmpm_uniforms *u);
  * polygon_vertex_count > 16 is FLOWMPM_ERR_INVALID. */
 int flowmpm_set_mode_uniforms(flowmpm_sim *sim, const flowmpm_mode_uniforms *m);
 
+/* Tuning of the tiled algorithms (no reference counterpart; results never depend on any of them).
+ * RIDE_REBINS: how flowmpm_step of a single-domain FLOWMPM_ALGO_TILED handle re-bins -- 2 (default) the
+ *   re-bin rides on the step and the step's mass pass counts the tiles, 1 it rides with a counting
+ *   launch of its own, 0 the standalone two-launch re-bin (what flowmpm_run_kernel and slab handles
+ *   always use).
+ * DRIFT_DIVISOR: the device re-bins when the particles outside their tile's arena, summed over the steps
+ *   since the last re-bin, exceed particles / divisor (default 8192 riding, 256 standalone, 48 on a slab;
+ *   0 leaves only rebin_interval).
+ * CHUNK: most particles per work item (256 .. 4096, default 4096).  SPARSE_TILE: tiles with fewer
+ *   particles than this get no work item and go down the follow-up kernels' path (default 0).  Both
+ *   force a re-bin at the next step. */
+#define FLOWMPM_OPTION_RIDE_REBINS   0
+#define FLOWMPM_OPTION_DRIFT_DIVISOR 1
+#define FLOWMPM_OPTION_CHUNK         2
+#define FLOWMPM_OPTION_SPARSE_TILE   3
+int flowmpm_set_option(flowmpm_sim *sim, int32_t option, int64_t value);
+
 /* renderer.computeAsync([...5 kernels]) (SIM:2538-2539), `n_steps` times.  The clock
  * of step k is (float)(uniforms.time + k * dtime).  Asynchronous: returns after
  * enqueueing; flowmpm_synchronize or any download waits. */
@@ -289,6 +306,13 @@ int flowmpm_stencil_mass_sum(flowmpm_sim *sim, int64_t *sum);
  * `planes` = grid_x entries (at most 8192).  What a host cuts balanced slabs from (summed over the
  * slabs of a decomposed run). */
 int flowmpm_plane_histogram(flowmpm_sim *sim, int64_t *out, int32_t planes);
+
+/* The same histogram for particles [first_id, first_id + count) of a generated scene
+ * (flowmpm_generate_particles) in a grid of grid[0] x grid[1] x grid[2] cells, computed on `device`
+ * straight from the generator: no handle and no particle store is needed, so a host can choose the
+ * slab boundaries before it creates the slab handles. */
+int flowmpm_scene_plane_histogram(int32_t device, int32_t scene, uint32_t seed, int64_t first_id,
+                                  int64_t count, const int32_t grid[3], double fill, int64_t *out);
 
 /* sizeof of the public structs as this library was compiled: flowmpm_config, flowmpm_uniforms,
  * flowmpm_mode_uniforms, flowmpm_timings.  A binding that re-declares them (ctypes, a typed-array

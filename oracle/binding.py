@@ -98,7 +98,6 @@ def lib():
         ip = ctypes.POINTER(ctypes.c_int32)
         up = ctypes.POINTER(Uniforms)
         L.orc_set_threads.argtypes = [ctypes.c_int]
-        L.orc_set_contracted_g2p.argtypes = [ctypes.c_int]
         L.orc_get_threads.restype = ctypes.c_int
         L.orc_clear_grid.argtypes = [ip, fp, ctypes.c_int64]
         L.orc_p2g1.argtypes = [fp, ip, up]
@@ -114,12 +113,6 @@ def lib():
         L.orc_tri_noise3d.argtypes = [fp, ctypes.c_float, ctypes.c_float, fp]
         _lib = L
     return _lib
-
-
-def set_contracted_g2p(on):
-    """Experiment only: g2p's affine sums as fused multiply-adds (the mirror of a device library built with
-    -DFLOWMPM_G2P_FMA=1).  Off by default; switch it off again after use."""
-    lib().orc_set_contracted_g2p(1 if on else 0)
 
 
 def _fp(a):

@@ -18,10 +18,6 @@ static int g_threads = 1;
 
 void orc_set_threads(int threads) { g_threads = threads < 1 ? 1 : threads; }
 
-/* Experiment only: the affine sums of g2p's gather (SIM:1340-1350) as fused multiply-adds, the mirror of
- * the device library built with -DFLOWMPM_G2P_FMA=1.  Off by default: the oracle contracts nothing. */
-static int g_contract_g2p = 0;
-void orc_set_contracted_g2p(int on) { g_contract_g2p = on ? 1 : 0; }
 int orc_get_threads(void) { return g_threads; }
 
 /* SIM:43 fixedPointMultiplier = 1e7 (exactly representable in f32). */
@@ -294,7 +290,7 @@ static void g2p_one(float *P, const float *cellf, const orc_uniforms *u)
                 float wv[3] = { f[0] * weight, f[1] * weight, f[2] * weight };
                 for (int c = 0; c < 3; c++)
                     for (int r = 0; r < 3; r++)
-                        B[c][r] = g_contract_g2p ? fmaf(wv[r], d[c], B[c][r]) : B[c][r] + wv[r] * d[c];
+                        B[c][r] = B[c][r] + wv[r] * d[c];
                 for (int r = 0; r < 3; r++) v[r] = v[r] + wv[r];
             }
 

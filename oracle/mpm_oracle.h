@@ -99,8 +99,6 @@ void orc_p2g1(const float *particles, int32_t *cell, const orc_uniforms *u);
 void orc_p2g2(float *particles, int32_t *cell, const orc_uniforms *u);
 void orc_update_grid(const int32_t *cell, float *cellf, const orc_uniforms *u);
 void orc_g2p(float *particles, const float *cellf, const orc_uniforms *u);
-/* Experiment only (off by default): g2p's affine sums as fused multiply-adds, see mpm_oracle.c. */
-void orc_set_contracted_g2p(int on);
 /* g2p with every mode branch of SIM:431-1536, the hide-percentage edge parking included;
  * u->grid_mode, u->front_gravity_mode and u->hide_percentage are honoured (u->num_particles
  * is uniforms.numParticles).  m == NULL means all mode uniforms are zero. */

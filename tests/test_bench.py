@@ -137,6 +137,11 @@ def test_the_single_gpu_line():
     assert steady["min"] <= steady["value"] <= max(steady["windows"])
     assert d["rebin_in_window"] == (d["rebin"]["performed"] > 0)
     assert d["kernels"]["p2g_with_sort"]["window"] == "steady"
+    # the line's roofline is the steady one; the timed window's figure rides along
+    assert roof["window"].startswith("steady") and d["value_steady"] == steady["value"]
+    assert set(roof["first_window"]) == {"kernel", "achieved", "frac", "avg_launch_ms"}
+    assert abs(roof["avg_launch_ms"] - sum(steady["kernel_avg_ms"][k] for k in
+                                           (("p2g1", "p2g2") if roof["kernel"] == "p2g" else (roof["kernel"],)))) < 2e-4
     assert "frac" not in d["kernels"]["clearGrid"] and "frac" in d["kernels"]["g2p"]
     assert roof["traffic"] is None and roof["traffic_source"] is None       # this workload was never profiled
 

@@ -8,6 +8,6 @@ for v in "$@"; do
 import json
 d = json.load(open("gpurun_out/ab_$v.json"))
 print("%-10s %6.2f Gps %6.3f ms " % ("$v", d["value"] / 1e9, d["ms_per_step"]),
-      {k: x["avg_ms"] for k, x in d["kernels"].items()}, "rebins", d["rebin"]["performed"], "ms each %.3f" % (d["rebin"]["performed_ms"] / max(d["rebin"]["performed"], 1)))
+      {k: x["avg_ms"] for k, x in d["kernels"].items()}, "rebins", d["rebin"]["performed"], "ms each %.3f" % (d["rebin"]["scan_ms"] / max(d["rebin"]["performed"], 1)))
 PY
 done
