@@ -49,6 +49,8 @@ EXPORTS = (
     "flowmpm_set_domain_particles", "flowmpm_get_allocation_count",
     "flowmpm_download_field_static", "flowmpm_generate_particles", "flowmpm_plane_histogram",
     "flowmpm_stencil_mass_sum", "flowmpm_abi_sizes", "flowmpm_scene_plane_histogram", "flowmpm_set_option",
+    "flowmpm_slab_step_begin", "flowmpm_slab_step_pack_mass", "flowmpm_slab_step_interior",
+    "flowmpm_slab_step_boundary", "flowmpm_slab_step_grid", "flowmpm_slab_step_end",
 )
 SCENE_ELLIPSOID, SCENE_DAM_BREAK = 0, 1
 OPTION_RIDE_REBINS, OPTION_DRIFT_DIVISOR, OPTION_CHUNK, OPTION_SPARSE_TILE = range(4)
@@ -181,6 +183,12 @@ def load():
         "flowmpm_stencil_mass_sum": ([vp, i64p], ctypes.c_int),
         "flowmpm_abi_sizes": ([i64p], ctypes.c_int),
         "flowmpm_set_option": ([vp, i32, i64], ctypes.c_int),
+        "flowmpm_slab_step_begin": ([vp], ctypes.c_int),
+        "flowmpm_slab_step_pack_mass": ([vp, vp, vp], ctypes.c_int),
+        "flowmpm_slab_step_interior": ([vp], ctypes.c_int),
+        "flowmpm_slab_step_boundary": ([vp, vp, vp, vp, vp], ctypes.c_int),
+        "flowmpm_slab_step_grid": ([vp], ctypes.c_int),
+        "flowmpm_slab_step_end": ([vp, vp, vp, ip, i32, vp], ctypes.c_int),
         "flowmpm_scene_plane_histogram": ([i32, i32, u32, i64, i64, ip, ctypes.c_double, i64p], ctypes.c_int),
     }
     for name, (argtypes, restype) in protos.items():

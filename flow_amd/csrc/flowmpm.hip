@@ -65,6 +65,8 @@ struct EventPair {
 
 }  // namespace
 
+constexpr int kSlabRideDivisor = 2048;
+
 struct flowmpm_sim {
     flowmpm_config cfg{};
     mpm::Params params{};
@@ -109,6 +111,7 @@ struct flowmpm_sim {
     // and whether that pass has run on the current particles.
     long long arrivals_first = -1;
     bool stayers_done = false;
+    int slab_phase = 0;          // which flowmpm_slab_step_* call comes next (0: _begin)
     int mass_bit(const int *buffer) const { return buffer == mass_first ? 2 : 4; }
     mpm::FixedGrid fixed() const
     {
@@ -341,7 +344,9 @@ inline bool is_tiled(const flowmpm_sim *s) { return s->cfg.algorithm != FLOWMPM_
 
 // The two-pass p2g of the tiled algorithm; `momentum` selects the pass.  stayers_only: the mass
 // pass without the particles that have left the slab's owned planes.
-int stage_p2g_pass(flowmpm_sim *s, bool momentum, bool stayers_only = false, int part = 0)
+// defer_scan: a re-bin that rides on a slab step counts its arrivals after this pass; the launch that builds the
+// next item set then follows the arrivals' mass pass (stage_p2g_mass_arrivals).
+int stage_p2g_pass(flowmpm_sim *s, bool momentum, bool stayers_only = false, int part = 0, bool defer_scan = false)
 {
     int rc;
     if (!is_tiled(s)) return fail(s, FLOWMPM_ERR_INVALID, "the mass/momentum passes belong to the tiled algorithm");
@@ -361,7 +366,7 @@ int stage_p2g_pass(flowmpm_sim *s, bool momentum, bool stayers_only = false, int
         rc = momentum ? mpm::launch_p2g_momentum_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream,
                                                        t.start, t.stop, s->stage_part(part))
                       : mpm::launch_p2g_mass_tiled(s->tiled, s->store, s->live, s->fixed(), s->params, s->stream,
-                                                   t.start, t.stop, keep_lo, keep_hi);
+                                                   t.start, t.stop, keep_lo, keep_hi, defer_scan);
         if (rc) return fail(s, FLOWMPM_ERR_HIP, "p2g pass: could not reset the straggler counter");
         if ((rc = launch_check(s, momentum ? "p2g_momentum" : "p2g_mass"))) return rc;
         if (!momentum) s->tiles_marked = true;
@@ -381,10 +386,11 @@ int stage_p2g_mass_arrivals(flowmpm_sim *s)
         const long long count = s->live - first;
         hipLaunchKernelGGL(mpm::p2g_mass_range_kernel, dim3((unsigned)std::min<long long>(blocks_for(count, 256), 1024)),
                            dim3(256), 0, s->stream, s->store, (int)first, (int)s->live, s->fixed(), s->params,
-                           mpm::tile_dims(s->tiled));
+                           mpm::tile_dims(s->tiled), s->tiled.ctl, s->tiled.key, s->tiled.rank, s->tiled.tile_count);
         int rc = launch_check(s, "p2g_mass_arrivals");
         if (rc) return rc;
     }
+    mpm::launch_ride_scan(s->tiled, s->live, s->stream);       // of a riding re-bin whose scan was deferred to here
     s->tiles_marked = true;      // stayers and arrivals together are the resident particles
     return FLOWMPM_OK;
 }
@@ -722,14 +728,20 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
             // A slab takes in arrivals every step, all of them outside the binning until the next re-bin:
             // it pays to carry more of them for longer (measured on slabs of the 8-slab decomposition
             // of 2^27 particles: 256 -> 2.57, 96 -> 2.44, 48 -> 2.34, 24 -> 2.35, 12 -> 2.36 ms per step).
-            if (s->slab) s->drift_divisor = s->drift_divisor_standalone = 48;
-            s->ride_rebins = (!s->slab && c.algorithm == FLOWMPM_ALGO_TILED) ? 2 : 0;
+            if (s->slab) s->drift_divisor_standalone = 48;
+            // flowmpm_step and the flowmpm_slab_step_* sequence let a re-bin ride; stage-by-stage hosts never do
+            s->ride_rebins = c.algorithm == FLOWMPM_ALGO_TILED ? 2 : 0;
+            s->migration.riding = &s->tiled.ctl->riding;
+            s->migration.key = s->tiled.key;
+            s->migration.rank = s->tiled.rank;
             // A riding re-bin costs a fraction of a standalone one, and the step it rides on still runs on the old
             // binning: it pays to start it earlier (steady state of the benchmark scene, noise uniform 0 / 1:
             // divisor 256 -> 10.17 / 7.78e9 per second, 512 -> 10.24 / 7.98, 1024 -> 10.22 / 7.98, 2048 -> 10.28 / 8.04).
             // With the count in the mass pass and the constant columns in the momentum pass (0.30 ms per re-bin):
             // 1024 -> 10.22 / 8.38, 4096 -> 10.31 / 8.21, 8192 -> 10.35 / 8.45, 16384 -> 10.37 / 8.48.
-            if (s->ride_rebins) s->drift_divisor = 8192;
+            // A slab takes in a few thousand arrivals per step, all outside the binning until the next re-bin and
+            // each costing three stages of global atomics: with re-bins this cheap it re-bins every few steps.
+            if (s->ride_rebins) s->drift_divisor = s->slab ? kSlabRideDivisor : 8192;
             HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->dirty), (size_t)s->tiled.n_tiles * sizeof(int)));
             HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
         }
@@ -988,8 +1000,10 @@ int flowmpm_set_option(flowmpm_sim *s, int32_t option, int64_t value)
     switch (option) {
     case FLOWMPM_OPTION_RIDE_REBINS:
         if (value < 0 || value > 2) return fail(s, FLOWMPM_ERR_INVALID, "ride form must be 0, 1 or 2");
-        if (value != 0 && (s->slab || s->cfg.algorithm != FLOWMPM_ALGO_TILED))
-            return fail(s, FLOWMPM_ERR_UNSUPPORTED, "re-bins ride only on flowmpm_step of a single-domain two-pass handle");
+        if (value != 0 && s->cfg.algorithm != FLOWMPM_ALGO_TILED)
+            return fail(s, FLOWMPM_ERR_UNSUPPORTED, "re-bins ride only on the two-pass tiled algorithm");
+        if (value == 1 && s->slab)
+            return fail(s, FLOWMPM_ERR_UNSUPPORTED, "a slab's riding re-bin counts in its mass pass (form 2)");
         s->ride_rebins = (int)value;
         return FLOWMPM_OK;
     case FLOWMPM_OPTION_DRIFT_DIVISOR:
@@ -1439,6 +1453,113 @@ int flowmpm_halo_add(flowmpm_sim *s, int32_t side, uint32_t comp_mask, const voi
     return launch_check(s, "halo_add");
 }
 
+// ---- one slab step in six calls (see include/flowmpm.h) -----------------------------------
+
+static int slab_step_enter(flowmpm_sim *s, int phase, const char *name)
+{
+    if (!s->slab || s->cfg.algorithm != FLOWMPM_ALGO_TILED)
+        return fail(s, FLOWMPM_ERR_INVALID, std::string(name) + " is for slab handles of FLOWMPM_ALGO_TILED");
+    if (s->slab_phase != phase) {
+        static const char *const order[] = {"flowmpm_slab_step_begin", "flowmpm_slab_step_pack_mass", "flowmpm_slab_step_interior",
+                                            "flowmpm_slab_step_boundary", "flowmpm_slab_step_grid", "flowmpm_slab_step_end"};
+        const std::string want = order[s->slab_phase];
+        s->slab_phase = 0;
+        return fail(s, FLOWMPM_ERR_INVALID, std::string(name) + " out of order: " + want + " comes next");
+    }
+    return FLOWMPM_OK;
+}
+
+static int halo_side(flowmpm_sim *s, bool add, int32_t side, uint32_t mask, const void *buffer)
+{
+    if (!buffer) return FLOWMPM_OK;          // no neighbour on that side
+    return add ? flowmpm_halo_add(s, side, mask, buffer) : flowmpm_halo_pack(s, side, mask, const_cast<void *>(buffer));
+}
+
+int flowmpm_slab_step_begin(flowmpm_sim *s)
+{
+    CHECK_SIM(s);
+    int rc = slab_step_enter(s, 0, "flowmpm_slab_step_begin");
+    if (rc) return rc;
+    s->profiling = s->profile_stride > 0 && (s->profile_step++ % s->profile_stride) == 0;
+    if ((rc = stage_clear_grid(s, false))) return rc;
+    // the binning decision of the step; a re-bin rides on the passes that follow
+    if (s->live > 0 && (rc = stage_rebin_if_needed(s, true))) return rc;
+    if ((rc = stage_p2g_pass(s, false, true, 0, true))) return rc;
+    s->slab_phase = 1;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_slab_step_pack_mass(flowmpm_sim *s, void *send_low, void *send_high)
+{
+    CHECK_SIM(s);
+    int rc = slab_step_enter(s, 1, "flowmpm_slab_step_pack_mass");
+    if (rc) return rc;
+    s->slab_phase = 0;
+    if ((rc = stage_p2g_mass_arrivals(s))) return rc;
+    if ((rc = halo_side(s, false, FLOWMPM_SIDE_LOW, FLOWMPM_COMP_MASS, send_low))) return rc;
+    if ((rc = halo_side(s, false, FLOWMPM_SIDE_HIGH, FLOWMPM_COMP_MASS, send_high))) return rc;
+    s->slab_phase = 2;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_slab_step_interior(flowmpm_sim *s)
+{
+    CHECK_SIM(s);
+    int rc = slab_step_enter(s, 2, "flowmpm_slab_step_interior");
+    if (rc) return rc;
+    s->slab_phase = 0;
+    if ((rc = stage_p2g_pass(s, true, false, 1))) return rc;
+    s->slab_phase = 3;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_slab_step_boundary(flowmpm_sim *s, const void *recv_low, const void *recv_high, void *send_low,
+                               void *send_high)
+{
+    CHECK_SIM(s);
+    int rc = slab_step_enter(s, 3, "flowmpm_slab_step_boundary");
+    if (rc) return rc;
+    s->slab_phase = 0;
+    if ((rc = halo_side(s, true, FLOWMPM_SIDE_LOW, FLOWMPM_COMP_MASS, recv_low))) return rc;
+    if ((rc = halo_side(s, true, FLOWMPM_SIDE_HIGH, FLOWMPM_COMP_MASS, recv_high))) return rc;
+    if ((rc = stage_p2g_pass(s, true, false, 2))) return rc;
+    if ((rc = halo_side(s, false, FLOWMPM_SIDE_LOW, FLOWMPM_COMP_MOMENTUM, send_low))) return rc;
+    if ((rc = halo_side(s, false, FLOWMPM_SIDE_HIGH, FLOWMPM_COMP_MOMENTUM, send_high))) return rc;
+    s->slab_phase = 4;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_slab_step_grid(flowmpm_sim *s)
+{
+    CHECK_SIM(s);
+    int rc = slab_step_enter(s, 4, "flowmpm_slab_step_grid");
+    if (rc) return rc;
+    s->slab_phase = 0;
+    if ((rc = stage_update_grid(s))) return rc;
+    if ((rc = stage_g2p(s, 1))) return rc;
+    s->slab_phase = 5;
+    return FLOWMPM_OK;
+}
+
+int flowmpm_slab_step_end(flowmpm_sim *s, const void *recv_low, const void *recv_high, const int32_t *plane_starts,
+                          int32_t n_ranks, void *dev_counts)
+{
+    CHECK_SIM(s);
+    int rc = slab_step_enter(s, 5, "flowmpm_slab_step_end");
+    if (rc) return rc;
+    s->slab_phase = 0;
+    if ((rc = halo_side(s, true, FLOWMPM_SIDE_LOW, FLOWMPM_COMP_MOMENTUM, recv_low))) return rc;
+    if ((rc = halo_side(s, true, FLOWMPM_SIDE_HIGH, FLOWMPM_COMP_MOMENTUM, recv_high))) return rc;
+    if (recv_low || recv_high) {
+        if ((rc = stage_update_grid(s, true))) return rc;
+    }
+    if ((rc = stage_g2p(s, 2))) return rc;
+    if (s->profiling && s->events_used > 4096 && (rc = timing_collect(s))) return rc;      // bound the live event pairs
+    s->profiling = s->profile_stride > 0;
+    if (plane_starts) return flowmpm_find_leavers(s, plane_starts, n_ranks, dev_counts);
+    return FLOWMPM_OK;
+}
+
 int flowmpm_extract_leavers(flowmpm_sim *s, const int32_t *plane_starts, int32_t n_ranks, void *dev_out,
                             int64_t capacity_records, int64_t *counts)
 {
@@ -1486,6 +1607,14 @@ int flowmpm_pack_leavers(flowmpm_sim *s, const int64_t *counts, int32_t n_ranks,
     for (int r = 0; r < n_ranks; r++)
         if (counts[r] < 0 || counts[r] > s->resident) return fail(s, FLOWMPM_ERR_INVALID, "bad counts");
     std::string msg;
+    // A re-bin between the classification and this call has moved the particles: the device repeats the
+    // classification on the slots they occupy now, if and only if that happened (the store's binning epoch).
+    if (s->tiled.ctl && s->migration.classified == s->resident && s->migration.table.n == n_ranks) {
+        const mpm::RankTable table = s->migration.table;        // find_leavers rewrites the scratch's copy
+        if (mpm::find_leavers(s->migration, s->store, s->resident, s->cfg.slab_x0, s->cfg.slab_nx, table.starts, n_ranks,
+                              nullptr, &s->tiled.ctl->epoch, true, s->stream, &msg))
+            return fail(s, FLOWMPM_ERR_HIP, "pack_leavers: " + msg);
+    }
     long long new_resident = s->resident;
     int rc = mpm::pack_leavers(s->migration, s->store, s->resident, s->cfg.slab_x0, s->cfg.slab_nx, counts, n_ranks,
                                reinterpret_cast<float *>(dev_out), capacity_records, s->stream, &new_resident, &msg);

@@ -140,8 +140,11 @@ find_movers_kernel(StoreSel ss, long long new_n, long long n, int x0, int nx, in
     if (!is_leaver(st.slot(kPosX)[j], x0, nx)) movers[atomicAdd(&counters[kMaxRanks + 2], 1)] = (int)j;
 }
 
+// riding (may be null): a device word that is 2 while a re-bin rides on the step and its mass pass has
+// already counted these particles; their tile key and rank (per slot) then move with them.
 __global__ void __launch_bounds__(256)
-fill_holes_kernel(StoreSel ss, const int *holes, const int *movers, const int *counters)
+fill_holes_kernel(StoreSel ss, const int *holes, const int *movers, const int *counters, const int *riding,
+                  int *__restrict__ key, int *__restrict__ rank)
 {
     const Store st = ss.pick();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,6 +153,7 @@ fill_holes_kernel(StoreSel ss, const int *holes, const int *movers, const int *c
     long long dst = holes[i], src = movers[i];
 #pragma unroll
     for (int w = 0; w < kRecordWords; w++) st.slot(w)[dst] = st.slot(w)[src];
+    if (riding && *riding == 2) { key[dst] = key[src]; rank[dst] = rank[src]; }
 }
 
 __global__ void __launch_bounds__(256)
@@ -171,6 +175,9 @@ __global__ void export_counts_kernel(const int *__restrict__ counters, int n_ran
 }
 
 struct MigrationScratch {
+    // of the handle's binning, for fill_holes_kernel (null on a handle without binning)
+    const int *riding = nullptr;
+    int *key = nullptr, *rank = nullptr;
     int *counters = nullptr;      // kCounterWords device words
     int *lists = nullptr;         // 5 device arrays of list_cap ints
     long long list_cap = 0;
@@ -281,7 +288,8 @@ inline int pack_leavers(MigrationScratch &M, StoreSel st, long long n, int x0, i
     const long long new_n = n - total;
     hipLaunchKernelGGL(find_holes_kernel, dim3(tb), dim3(256), 0, stream, list_slot, (int)total, new_n, M.counters, holes);
     hipLaunchKernelGGL(find_movers_kernel, dim3(tb), dim3(256), 0, stream, st, new_n, n, x0, nx, M.counters, movers);
-    hipLaunchKernelGGL(fill_holes_kernel, dim3(tb), dim3(256), 0, stream, st, holes, movers, M.counters);
+    hipLaunchKernelGGL(fill_holes_kernel, dim3(tb), dim3(256), 0, stream, st, holes, movers, M.counters, M.riding,
+                       M.key, M.rank);
     if ((e = hipGetLastError()) != hipSuccess) { *msg = std::string("compact: ") + hipGetErrorString(e); return 1; }
     *new_resident = new_n;
     return 0;

@@ -922,9 +922,12 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     unsigned touched = 0;
     for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
         Stencil s = make_stencil(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j]);
+        // a slab's leavers (floor(x) outside the planes it owns) are about to be packed away: they are neither
+        // scattered nor counted
+        const bool leaver = s.cx + 1 < w.keep_lo || s.cx + 1 >= w.keep_hi;       // s.cx = floor(x) - 1
         if (counting) {
             int abase_unused;
-            if (!stencil_in_arena(s, A, &abase_unused)) {
+            if (leaver || !stencil_in_arena(s, A, &abase_unused)) {
                 w.rank[j] = kRankNotMine;
             } else {
                 // tile of floor(position) = s.c + 1; inside the arena it is this tile or one next to it
@@ -937,7 +940,7 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
                 w.rank[j] = (nb << kRankNbShift) | atomicAdd(&nb_count[nb], 1);
             }
         }
-        if (s.cx + 1 < w.keep_lo || s.cx + 1 >= w.keep_hi) continue;       // s.cx = floor(x) - 1
+        if (leaver) continue;
         int abase;
         if (stencil_in_arena(s, A, &abase)) {
             p2g_mass_particle<true>(s, lds, abase, g, P);
@@ -1339,7 +1342,7 @@ straggler_p2g_team_kernel(TiledWork w, FixedGrid g, Params P)
         if (!MOMENTUM) {
             if (cell >= 0) atomicAdd(g.mass + cell, encode_fixed(weight));
             // a riding re-bin counts in the mass pass: the particles the tiled kernel left to this one
-            if (live && c == 0 && w.ctl->riding == 2) {
+            if (mine && c == 0 && w.ctl->riding == 2) {         // (`mine` excludes a slab's leavers)
                 const int k = tile_of(px, py, pz, P, w.td);
                 w.key[j] = k;
                 w.rank[j] = atomicAdd(&w.tile_count[k], 1);
@@ -1699,9 +1702,22 @@ inline int launch_p2g2_tiled(TiledState &T, StoreSel st, long long n, FixedGrid 
 }
 
 // keep_lo / keep_hi: see TiledWork.
+// The launch that turns the tile counts of a riding re-bin into the next item set (a no-op on the device
+// when the mass pass found no re-bin due).  n: the particles counted.
+inline void launch_ride_scan(TiledState &T, long long n, hipStream_t stream)
+{
+    if (!T.scan_after_mass) return;
+    T.scan_after_mass = false;
+    hipExtLaunchKernelGGL(ride_scan_kernel, dim3(1), dim3(1024), 0, stream, T.scan_ev_start, T.scan_ev_stop, 0, T.ctl,
+                          T.tile_count, T.n_tiles, T.tile_start, T.items, T.n_items, T.item_cap, T.chunk, (int)n,
+                          T.sparse);
+}
+
+// defer_scan: the caller launches the scan itself (launch_ride_scan), after it has counted the particles
+// this pass does not see (a slab's arrivals).
 inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream,
                                  hipEvent_t ev_start, hipEvent_t ev_stop, int keep_lo = -2147483647 - 1,
-                                 int keep_hi = 2147483647)
+                                 int keep_hi = 2147483647, bool defer_scan = false)
 {
     T.listed = -1;      // this stage overwrites the one straggler list: a momentum pass's list is gone
     TiledWork w = tiled_work(T, st, n);
@@ -1715,25 +1731,30 @@ inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedG
     hipExtLaunchKernelGGL(p2g_mass_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, ev_start,
                           ev_stop, 0, w, g, P);
     hipLaunchKernelGGL(straggler_p2g_team_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
-    if (T.scan_after_mass) {
-        T.scan_after_mass = false;
-        hipExtLaunchKernelGGL(ride_scan_kernel, dim3(1), dim3(1024), 0, stream, T.scan_ev_start, T.scan_ev_stop, 0, T.ctl,
-                              T.tile_count, T.n_tiles, T.tile_start, T.items, T.n_items, T.item_cap, T.chunk, (int)n,
-                              T.sparse);
-    }
+    if (!defer_scan) launch_ride_scan(T, n, stream);
     return 0;
 }
 
 // The mass pass for the particles in slots [first, n) alone (a slab's arrivals, inserted after
 // its mass pass ran), straight to the global grid.
+// While a re-bin rides on the step whose mass pass counts the tiles (RebinCtl::riding == 2) these
+// particles are counted here: they arrived after that pass.
 __global__ void __launch_bounds__(256)
-p2g_mass_range_kernel(StoreSel ss, int first, int n, FixedGrid g, Params P, TileDims td)
+p2g_mass_range_kernel(StoreSel ss, int first, int n, FixedGrid g, Params P, TileDims td, const RebinCtl *ctl,
+                      int *__restrict__ key, int *__restrict__ rank, int *__restrict__ tile_count)
 {
     const Store st = ss.pick();
+    const bool counting = ctl->riding == 2;
     for (int j = first + blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        Stencil s = make_stencil(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j]);
+        const float px = st.slot(kPosX)[j], py = st.slot(kPosY)[j], pz = st.slot(kPosZ)[j];
+        Stencil s = make_stencil(px, py, pz);
         mark_dirty_stencil(s, td, P, g);
         p2g_mass_particle<false>(s, nullptr, 0, g, P);
+        if (counting) {
+            const int k = tile_of(px, py, pz, P, td);
+            key[j] = k;
+            rank[j] = atomicAdd(&tile_count[k], 1);
+        }
     }
 }
 

@@ -269,6 +269,32 @@ class Handle:
             self._h, counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), counts.shape[0],
             ctypes.c_void_p(dev_out), int(capacity_records)))
 
+    # one slab step in six calls (include/flowmpm.h); buffers are device addresses, 0 / None = no neighbour
+    def slab_step_begin(self):
+        self._chk(self.L.flowmpm_slab_step_begin(self._h))
+
+    def slab_step_pack_mass(self, send_low, send_high):
+        self._chk(self.L.flowmpm_slab_step_pack_mass(self._h, ctypes.c_void_p(send_low), ctypes.c_void_p(send_high)))
+
+    def slab_step_interior(self):
+        self._chk(self.L.flowmpm_slab_step_interior(self._h))
+
+    def slab_step_boundary(self, recv_low, recv_high, send_low, send_high):
+        self._chk(self.L.flowmpm_slab_step_boundary(self._h, ctypes.c_void_p(recv_low), ctypes.c_void_p(recv_high),
+                                                    ctypes.c_void_p(send_low), ctypes.c_void_p(send_high)))
+
+    def slab_step_grid(self):
+        self._chk(self.L.flowmpm_slab_step_grid(self._h))
+
+    def slab_step_end(self, recv_low, recv_high, plane_starts=None, dev_counts=None):
+        if plane_starts is None:
+            starts, n_ranks = None, 0
+        else:
+            arr = np.ascontiguousarray(plane_starts, dtype=np.int32)
+            starts, n_ranks = _ip(arr), arr.shape[0] - 1
+        self._chk(self.L.flowmpm_slab_step_end(self._h, ctypes.c_void_p(recv_low), ctypes.c_void_p(recv_high), starts,
+                                               n_ranks, ctypes.c_void_p(dev_counts)))
+
     def insert_arrivals(self, dev_in, count):
         self._chk(self.L.flowmpm_insert_arrivals(self._h, ctypes.c_void_p(dev_in), int(count)))
 

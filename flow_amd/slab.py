@@ -189,6 +189,12 @@ class GpuSlabBackend:
         self.handle.find_leavers(plane_starts, self._counts.data_ptr())
         return self._counts
 
+    def counts_tensor(self, world):
+        """The device tensor the classification at the end of a step writes its counts into."""
+        if self._counts is None or self._counts.shape[0] != world:
+            self._counts = torch.zeros(world, dtype=torch.int64, device=self.torch_device)
+        return self._counts
+
     def refind_leavers(self, plane_starts):
         """The classification again, on the slots the particles occupy now (a re-bin may have
         moved them since find_leavers); the counts are the same and are not exported again."""
@@ -240,7 +246,7 @@ class SlabSimulation:
         # The library's tiled mass pass can skip the leavers itself and add the arrivals later, so it
         # is enqueued before the host waits for the migration counts.
         # (FLOWMPM_SLAB_OVERLAP=0 keeps every stage whole, for A/B runs on a multi-GPU node.)
-        self.split_mass_pass = fused and world > 1 and os.environ.get("FLOWMPM_SLAB_OVERLAP", "1") != "0"
+        self.split_mass_pass = fused and os.environ.get("FLOWMPM_SLAB_OVERLAP", "1") != "0"
         self.low = rank - 1 if rank > 0 else None
         self.high = rank + 1 if rank < world - 1 else None
         b = self.backend
@@ -377,16 +383,20 @@ class SlabSimulation:
         if self.transport is None:
             return
         self._pending_counts = self.backend.find_leavers(self.plane_starts)
-        if self.early_counts:
-            try:
-                self._pending_matrix = self._start_count_gather(self._pending_counts)
-            except (RuntimeError, TypeError, NotImplementedError) as exc:
-                # every rank runs the same library, so every rank lands here together; the
-                # exchange then happens where the counts are needed
-                print("flow_amd.slab: early count exchange unavailable (%s); using the blocking one"
-                      % (str(exc).splitlines()[0] if str(exc) else type(exc).__name__), file=sys.stderr)
-                self.early_counts = False
-                self._pending_matrix = None
+        self._start_early_counts()
+
+    def _start_early_counts(self):
+        if not self.early_counts:
+            return
+        try:
+            self._pending_matrix = self._start_count_gather(self._pending_counts)
+        except (RuntimeError, TypeError, NotImplementedError) as exc:
+            # every rank runs the same library, so every rank lands here together; the
+            # exchange then happens where the counts are needed
+            print("flow_amd.slab: early count exchange unavailable (%s); using the blocking one"
+                  % (str(exc).splitlines()[0] if str(exc) else type(exc).__name__), file=sys.stderr)
+            self.early_counts = False
+            self._pending_matrix = None
 
     def _start_count_gather(self, counts_dev):
         """The count exchange and its copy to the host, started as soon as the classification is
@@ -475,8 +485,8 @@ class SlabSimulation:
     def step(self):
         b = self.backend
         p2g = self.p2g_kernels
-        b.run_kernel(self.clear_kernel)           # touches no particle: runs while the counts travel
         if not self.split_mass_pass:
+            b.run_kernel(self.clear_kernel)           # touches no particle: runs while the counts travel
             self._finish_migration()
             b.run_kernel(p2g[0])
             self._exchange_planes(_lib.COMP_MASS)
@@ -486,29 +496,50 @@ class SlabSimulation:
             b.run_kernel(_lib.KERNEL_G2P)
             self._begin_migration()
             return
-        # The library's tiled stages in parts, so that neither the host's wait for the migration
-        # counts nor a halo exchange leaves the GPU without work.  The mass pass of the particles
-        # that stay runs while the counts travel: the leavers are skipped on the device, the
-        # arrivals added once they are in.
-        b.run_kernel(_lib.KERNEL_P2G_MASS_STAYERS)
-        if self._pending_counts is not None:
-            b.refind_leavers(self.plane_starts)
+        # The library's tiled stages in six calls (flowmpm_slab_step_*), so that neither the host's wait for
+        # the migration counts nor a halo exchange leaves the GPU without work: the mass pass of the
+        # particles that stay runs while the counts travel (the leavers are skipped on the device, the
+        # arrivals added once they are in); the mass halo travels while the work items that cannot see the
+        # boundary planes run their momentum pass; the momentum halo travels during updateGrid and the
+        # interior part of g2p, and updateGrid is repeated over the boundary tiles once it has been added.
+        h = b.handle
+        ptr = lambda side, m, bufs: bufs[side, m].data_ptr() if (self.low if side == "low" else self.high) is not None else None
+        MASS, MOM = _lib.COMP_MASS, _lib.COMP_MOMENTUM
+        h.slab_step_begin()
         self._finish_migration()
-        b.run_kernel(_lib.KERNEL_P2G_MASS_ARRIVALS)
-        # the mass halo travels while the work items that cannot see the boundary planes run
-        mass_halo = self._post_planes(_lib.COMP_MASS)
-        b.run_kernel(_lib.KERNEL_P2G_MOMENTUM_INTERIOR)
-        self._add_planes(_lib.COMP_MASS, mass_halo)
-        b.run_kernel(_lib.KERNEL_P2G_MOMENTUM_BOUNDARY)
-        # the momentum halo travels during updateGrid and the interior part of g2p; updateGrid is
-        # repeated over the boundary tiles once it has been added
-        momentum_halo = self._post_planes(_lib.COMP_MOMENTUM)
-        b.run_kernel(_lib.KERNEL_UPDATE_GRID)
-        b.run_kernel(_lib.KERNEL_G2P_INTERIOR)
-        self._add_planes(_lib.COMP_MOMENTUM, momentum_halo)
-        b.run_kernel(_lib.KERNEL_UPDATE_GRID_BOUNDARY)
-        b.run_kernel(_lib.KERNEL_G2P_BOUNDARY)
-        self._begin_migration()
+        h.slab_step_pack_mass(ptr("low", MASS, self._send), ptr("high", MASS, self._send))
+        mass_halo = self._post_halo(MASS)
+        h.slab_step_interior()
+        self._complete(mass_halo)
+        h.slab_step_boundary(ptr("low", MASS, self._recv), ptr("high", MASS, self._recv),
+                             ptr("low", MOM, self._send), ptr("high", MOM, self._send))
+        momentum_halo = self._post_halo(MOM)
+        h.slab_step_grid()
+        self._complete(momentum_halo)
+        if self.transport is None:
+            h.slab_step_end(None, None)
+            return
+        counts = b.counts_tensor(self.world)
+        h.slab_step_end(ptr("low", MOM, self._recv), ptr("high", MOM, self._recv), self.plane_starts, counts.data_ptr())
+        self._pending_counts = counts
+        self._start_early_counts()
+
+    def _post_halo(self, mask):
+        """Starts the exchange of the halo pairs the library has packed into the send buffers."""
+        if self.transport is None:
+            return None
+        sends, recvs = [], []
+        if self.low is not None:
+            sends.append((self._send["low", mask], self.low))
+            recvs.append((self._recv["low", mask], self.low))
+        if self.high is not None:
+            sends.append((self._send["high", mask], self.high))
+            recvs.append((self._recv["high", mask], self.high))
+        return self.transport.post(sends, recvs)
+
+    def _complete(self, posted):
+        if self.transport is not None:
+            self.transport.complete(posted)
 
     def resident(self):
         self._finish_migration()
@@ -593,8 +624,6 @@ class LocalSlabGroup:
         if not self._pending:
             return
         self._pending = False
-        for b in self.backends:
-            b.refind_leavers(self.plane_starts)
         matrix = self.torch.stack([b._counts for b in self.backends]).cpu().numpy()      # the one host wait
         packed = [b.pack_leavers(matrix[r]) for r, b in enumerate(self.backends)]
         for r in range(self.world):
@@ -604,23 +633,36 @@ class LocalSlabGroup:
                 self.max_hop = max(self.max_hop, abs(int(peer) - r))
                 self.backends[peer].insert_arrivals(packed[r][int(offs[peer]):int(offs[peer + 1])])
 
+    def _buf(self, r, side, mask):
+        """Slab r's own packed halo pair of `side` (None at the ends of the domain)."""
+        if (side == _lib.SIDE_LOW and r == 0) or (side == _lib.SIDE_HIGH and r == self.world - 1):
+            return None
+        return self._halo[r][side, mask].data_ptr()
+
+    def _from(self, r, side, mask):
+        """What slab r receives on `side`: the neighbour's packed pair of the facing side."""
+        if side == _lib.SIDE_LOW:
+            return self._buf(r - 1, _lib.SIDE_HIGH, mask) if r > 0 else None
+        return self._buf(r + 1, _lib.SIDE_LOW, mask) if r < self.world - 1 else None
+
     def step(self):
-        self._run(_lib.KERNEL_CLEAR_FIXED_GRID)
-        self._run(_lib.KERNEL_P2G_MASS_STAYERS)
+        LOW, HIGH, MASS, MOM = _lib.SIDE_LOW, _lib.SIDE_HIGH, _lib.COMP_MASS, _lib.COMP_MOMENTUM
+        hs = self.handles
+        for h in hs:
+            h.slab_step_begin()
         self._migrate()
-        self._run(_lib.KERNEL_P2G_MASS_ARRIVALS)
-        self._pack(_lib.COMP_MASS)
-        self._run(_lib.KERNEL_P2G_MOMENTUM_INTERIOR)
-        self._add(_lib.COMP_MASS)
-        self._run(_lib.KERNEL_P2G_MOMENTUM_BOUNDARY)
-        self._pack(_lib.COMP_MOMENTUM)
-        self._run(_lib.KERNEL_UPDATE_GRID)
-        self._run(_lib.KERNEL_G2P_INTERIOR)
-        self._add(_lib.COMP_MOMENTUM)
-        self._run(_lib.KERNEL_UPDATE_GRID_BOUNDARY)
-        self._run(_lib.KERNEL_G2P_BOUNDARY)
-        for b in self.backends:
-            b.find_leavers(self.plane_starts)
+        for r, h in enumerate(hs):
+            h.slab_step_pack_mass(self._buf(r, LOW, MASS), self._buf(r, HIGH, MASS))
+        for h in hs:
+            h.slab_step_interior()
+        for r, h in enumerate(hs):        # every mass pair has been packed: the merges may read them
+            h.slab_step_boundary(self._from(r, LOW, MASS), self._from(r, HIGH, MASS), self._buf(r, LOW, MOM),
+                                 self._buf(r, HIGH, MOM))
+        for h in hs:
+            h.slab_step_grid()
+        for r, (h, b) in enumerate(zip(hs, self.backends)):
+            h.slab_step_end(self._from(r, LOW, MOM), self._from(r, HIGH, MOM), self.plane_starts,
+                            b.counts_tensor(self.world).data_ptr())
         self._pending = True
 
     def finish(self):

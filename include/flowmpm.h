@@ -257,9 +257,10 @@ int flowmpm_set_mode_uniforms(flowmpm_sim *sim, const flowmpm_mode_uniforms *m);
  * RIDE_REBINS: how flowmpm_step of a single-domain FLOWMPM_ALGO_TILED handle re-bins -- 2 (default) the
  *   re-bin rides on the step and the step's mass pass counts the tiles, 1 it rides with a counting
  *   launch of its own, 0 the standalone two-launch re-bin (what flowmpm_run_kernel and slab handles
- *   always use).
+ *   always use).  The flowmpm_slab_step_* sequence of a slab handle rides in form 2 (or 0).
  * DRIFT_DIVISOR: the device re-bins when the particles outside their tile's arena, summed over the steps
- *   since the last re-bin, exceed particles / divisor (default 8192 riding, 256 standalone, 48 on a slab;
+ *   since the last re-bin, exceed particles / divisor (default 8192 riding, 2048 riding on a slab, 256
+ *   standalone, 48 standalone on a slab;
  *   0 leaves only rebin_interval).
  * CHUNK: most particles per work item (256 .. 4096, default 4096).  SPARSE_TILE: tiles with fewer
  *   particles than this get no work item and go down the follow-up kernels' path (default 0).  Both
@@ -395,6 +396,41 @@ int flowmpm_pack_leavers(flowmpm_sim *sim, const int64_t *counts, int32_t n_rank
                          int64_t capacity_records);
 /* Appends packed records that arrived from other ranks. */
 int flowmpm_insert_arrivals(flowmpm_sim *sim, const void *dev_in, int64_t count);
+
+/* ---- One step of a FLOWMPM_ALGO_TILED slab handle in six calls, in this order (any other order is
+ * FLOWMPM_ERR_INVALID).  Each call only enqueues; the gaps between them are where the host's transport
+ * acts.  This is the stage sequence above (clearGrid, mass pass of the stayers, ... g2p of the boundary
+ * items, classification of the leavers) with two differences: the host makes 6 calls per step instead of
+ * about 20, and, because the library owns the order of the stages, a re-bin found due RIDES on the step
+ * as it does in flowmpm_step -- the mass pass counts the tiles (arrivals included), the momentum pass
+ * and g2p store to the particles' new slots -- instead of moving every record in two launches of its own.
+ *
+ *   flowmpm_slab_step_begin          clearGrid of the fixed-point grid, mass pass of the particles that stay
+ *     [host: reads the migration counts, flowmpm_pack_leavers, sends / receives, flowmpm_insert_arrivals]
+ *   flowmpm_slab_step_pack_mass      mass pass of the arrivals; packs the mass halo of each side
+ *     [host: starts the exchange of the mass halo]
+ *   flowmpm_slab_step_interior       momentum pass of the work items that cannot see a boundary plane
+ *     [host: makes the stream wait for the mass halo]
+ *   flowmpm_slab_step_boundary       adds the received mass halo, momentum pass of the other items, packs
+ *                                    the momentum halo
+ *     [host: starts the exchange of the momentum halo]
+ *   flowmpm_slab_step_grid           updateGrid, g2p of the interior items
+ *     [host: makes the stream wait for the momentum halo]
+ *   flowmpm_slab_step_end            adds the received momentum halo, updateGrid over the boundary tiles
+ *                                    again, g2p of the other items, then flowmpm_find_leavers(plane_starts,
+ *                                    n_ranks, dev_counts) (skipped when plane_starts is NULL)
+ *
+ * send_* / recv_*: device buffers of flowmpm_halo_words(FLOWMPM_COMP_MASS resp. FLOWMPM_COMP_MOMENTUM)
+ * words; NULL where the slab has no neighbour.  flowmpm_pack_leavers repeats the classification by itself
+ * when a re-bin has moved the particles since flowmpm_find_leavers. */
+int flowmpm_slab_step_begin(flowmpm_sim *sim);
+int flowmpm_slab_step_pack_mass(flowmpm_sim *sim, void *send_low, void *send_high);
+int flowmpm_slab_step_interior(flowmpm_sim *sim);
+int flowmpm_slab_step_boundary(flowmpm_sim *sim, const void *recv_low, const void *recv_high,
+                               void *send_low, void *send_high);
+int flowmpm_slab_step_grid(flowmpm_sim *sim);
+int flowmpm_slab_step_end(flowmpm_sim *sim, const void *recv_low, const void *recv_high,
+                          const int32_t *plane_starts, int32_t n_ranks, void *dev_counts);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from helpers import DEFAULT_UNIFORMS, assert_bits_equal, moving_particles
-from flow_amd import _lib
+from flow_amd import Handle, _lib
 from flow_amd.slab import balanced_plane_starts, equal_plane_starts
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -350,3 +350,72 @@ def test_eight_rank_rehearsal_on_one_gpu(oracle_binding, tmp_path):
     assert moved > 0
     hops = [int(np.load(os.path.join(tmp_path, "rank%d.npz" % r))["max_hop"]) for r in range(8)]
     assert max(hops) >= 2, "no particle jumped over a whole slab: %r" % hops
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rebin_interval,ride", [(1, 2), (3, 2), (2, 0)], ids=["ride_every_step", "ride_every_third", "standalone"])
+def test_slab_step_calls_with_riding_rebins_match_single_domain(oracle_binding, rebin_interval, ride):
+    """The six-call slab step (flowmpm_slab_step_*) on eight slabs in one process: re-bins ride on the
+    step while particles leave (holes filled from the tail: tile keys and ranks move with the movers) and
+    arrive (counted by the arrivals' mass pass), with a time step large enough that some jump over whole
+    slabs -- against the single-domain oracle, bit for bit."""
+    from flow_amd.slab import LocalSlabGroup
+
+    grid, n, steps, dt = (142, 16, 24), 40000, 9, 1.0
+    starts = [0, 37, 48, 57, 66, 74, 83, 95, 142]
+    world = len(starts) - 1
+    rec = moving_particles(n, grid, seed=47, vel=3.0)
+    group = LocalSlabGroup(grid, starts, n, rebin_interval=rebin_interval)
+    dest = np.searchsorted(np.asarray(starts), np.floor(rec[:, 0]).astype(int), side="right") - 1
+    for r, b in enumerate(group.backends):
+        rows = np.nonzero(dest == r)[0]
+        b.upload(rec[rows], rows.astype(np.int32))
+        b.handle.set_option(_lib.OPTION_RIDE_REBINS, ride)
+    for k in range(steps):
+        group.set_uniforms(**dict(DEFAULT_UNIFORMS, dt=dt, time=0.25 * k))
+        group.step()
+    group.finish()
+    assert group.migrated > 0 and group.max_hop >= 2
+    rebins = [h.timings()["rebin"]["performed"] for h in group.handles]
+    assert min(rebins) >= (steps - 1) // rebin_interval, rebins
+
+    want = rec.copy()
+    orc = oracle_binding.Oracle(grid, threads=8)
+    for k in range(steps):
+        orc.step(want, oracle_binding.make_uniforms(grid, n, **dict(DEFAULT_UNIFORMS, dt=dt, time=0.25 * k)))
+    totals = group.conservation()
+    assert np.array_equal(totals[:4], orc.cell.astype(np.int64).sum(axis=0)) and int(totals[4]) == n
+    per = grid[1] * grid[2]
+    seen = np.zeros(n, bool)
+    for r, b in enumerate(group.backends):
+        got, ids = b.download()
+        assert not seen[ids].any()
+        seen[ids] = True
+        assert_bits_equal(got, want[ids], "slab %d particles" % r)
+        x0, x1 = starts[r], starts[r + 1]
+        assert np.array_equal(b.handle.download_grid_i32()[per:(x1 - x0 + 1) * per], orc.cell[x0 * per:x1 * per]), "slab %d grid" % r
+        assert_bits_equal(b.handle.download_grid_f32()[per:(x1 - x0 + 1) * per], orc.cellf[x0 * per:x1 * per], "slab %d float grid" % r)
+    assert seen.all()
+    group.close()
+
+
+@pytest.mark.gpu
+def test_slab_step_calls_out_of_order_are_refused():
+    h = Handle((32, 16, 16), 100, algorithm=_lib.ALGO_TILED, slab=(8, 16))
+    with pytest.raises(_lib.FlowMpmError) as err:
+        h.slab_step_interior()
+    assert err.value.code == _lib.ERR_INVALID and "flowmpm_slab_step_begin comes next" in str(err.value)
+    h.slab_step_begin()
+    with pytest.raises(_lib.FlowMpmError):
+        h.slab_step_grid()
+    h.slab_step_begin()          # a refused call starts the sequence over
+    h.slab_step_pack_mass(None, None)
+    h.slab_step_interior()
+    h.slab_step_boundary(None, None, None, None)
+    h.slab_step_grid()
+    h.slab_step_end(None, None)
+    h.close()
+    single = Handle((32, 16, 16), 100, algorithm=_lib.ALGO_TILED)
+    with pytest.raises(_lib.FlowMpmError):
+        single.slab_step_begin()
+    single.close()
