@@ -8,8 +8,8 @@ and of its caller (app).
 from . import _lib
 from .conf import Conf, conf
 from .app import App, run_headless
-from .simulator import Handle, MlsMpmSimulator, Vector3
+from .simulator import Handle, MlsMpmSimulator, SlabGroup, Vector3
 from .structured_array import PARTICLE_STRUCT, StructuredArray
 
-__all__ = ["_lib", "App", "run_headless", "Conf", "conf", "Handle", "MlsMpmSimulator", "Vector3", "PARTICLE_STRUCT",
+__all__ = ["_lib", "App", "run_headless", "Conf", "conf", "Handle", "MlsMpmSimulator", "SlabGroup", "Vector3", "PARTICLE_STRUCT",
            "StructuredArray"]

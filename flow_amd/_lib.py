@@ -51,6 +51,12 @@ EXPORTS = (
     "flowmpm_stencil_mass_sum", "flowmpm_abi_sizes", "flowmpm_scene_plane_histogram", "flowmpm_set_option",
     "flowmpm_slab_step_begin", "flowmpm_slab_step_pack_mass", "flowmpm_slab_step_interior",
     "flowmpm_slab_step_boundary", "flowmpm_slab_step_grid", "flowmpm_slab_step_end",
+    "flowmpm_slab_group_create", "flowmpm_slab_group_destroy", "flowmpm_slab_group_last_error",
+    "flowmpm_slab_group_size", "flowmpm_slab_group_slab", "flowmpm_slab_group_upload",
+    "flowmpm_slab_group_generate", "flowmpm_slab_group_set_uniforms", "flowmpm_slab_group_set_mode_uniforms",
+    "flowmpm_slab_group_step", "flowmpm_slab_group_synchronize", "flowmpm_slab_group_get_num_particles",
+    "flowmpm_slab_group_download_particles", "flowmpm_slab_group_download_field",
+    "flowmpm_slab_group_conservation", "flowmpm_slab_group_migration_stats", "flowmpm_rccl_selftest",
 )
 SCENE_ELLIPSOID, SCENE_DAM_BREAK = 0, 1
 OPTION_RIDE_REBINS, OPTION_DRIFT_DIVISOR, OPTION_CHUNK, OPTION_SPARSE_TILE = range(4)
@@ -189,6 +195,23 @@ def load():
         "flowmpm_slab_step_boundary": ([vp, vp, vp, vp, vp], ctypes.c_int),
         "flowmpm_slab_step_grid": ([vp], ctypes.c_int),
         "flowmpm_slab_step_end": ([vp, vp, vp, ip, i32, vp], ctypes.c_int),
+        "flowmpm_slab_group_create": ([ctypes.POINTER(Config), ip, i32, ip, i64p, ctypes.POINTER(vp)], ctypes.c_int),
+        "flowmpm_slab_group_destroy": ([vp], ctypes.c_int),
+        "flowmpm_slab_group_last_error": ([vp], ctypes.c_char_p),
+        "flowmpm_slab_group_size": ([vp, ip, ip], ctypes.c_int),
+        "flowmpm_slab_group_slab": ([vp, i32, ctypes.POINTER(vp)], ctypes.c_int),
+        "flowmpm_slab_group_upload": ([vp, fp, i64], ctypes.c_int),
+        "flowmpm_slab_group_generate": ([vp, i32, u32, i64, ctypes.c_double], ctypes.c_int),
+        "flowmpm_slab_group_set_uniforms": ([vp, ctypes.POINTER(Uniforms)], ctypes.c_int),
+        "flowmpm_slab_group_set_mode_uniforms": ([vp, ctypes.POINTER(ModeUniforms)], ctypes.c_int),
+        "flowmpm_slab_group_step": ([vp, i32, ctypes.c_double], ctypes.c_int),
+        "flowmpm_slab_group_synchronize": ([vp], ctypes.c_int),
+        "flowmpm_slab_group_get_num_particles": ([vp, i64p, i64p], ctypes.c_int),
+        "flowmpm_slab_group_download_particles": ([vp, fp, i64, i64p], ctypes.c_int),
+        "flowmpm_slab_group_download_field": ([vp, i32, fp, i64], ctypes.c_int),
+        "flowmpm_slab_group_conservation": ([vp, i64p], ctypes.c_int),
+        "flowmpm_slab_group_migration_stats": ([vp, i64p, ip], ctypes.c_int),
+        "flowmpm_rccl_selftest": ([i32, i64], ctypes.c_int),
         "flowmpm_scene_plane_histogram": ([i32, i32, u32, i64, i64, ip, ctypes.c_double, i64p], ctypes.c_int),
     }
     for name, (argtypes, restype) in protos.items():
@@ -209,6 +232,12 @@ def load():
 def check(handle, code):
     if code != OK:
         msg = load().flowmpm_last_error(handle)
+        raise FlowMpmError(code, msg.decode() if msg else "")
+
+
+def check_group(group, code):
+    if code != OK:
+        msg = load().flowmpm_slab_group_last_error(group)
         raise FlowMpmError(code, msg.decode() if msg else "")
 
 

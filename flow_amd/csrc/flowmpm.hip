@@ -65,7 +65,7 @@ struct EventPair {
 
 }  // namespace
 
-constexpr int kSlabRideDivisor = 2048;
+constexpr int kSlabRideDivisor = 512;      // measured on the 8 slabs of 2^27 particles / 512^3: 4096 -> 1.95, 2048 -> 1.96, 1024 -> 1.93, 512 -> 1.91 ms per slab step
 
 struct flowmpm_sim {
     flowmpm_config cfg{};
@@ -403,8 +403,15 @@ int stage_update_grid(flowmpm_sim *s, bool boundary_only = false)
     int rc = timing_events(s, FLOWMPM_KERNEL_UPDATE_GRID, &t, boundary_only);
     if (rc) return rc;
     unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
+    // over the boundary tiles alone: the launch holds the always-visited tile columns only
+    unsigned tile_blocks = (unsigned)s->tiled.n_tiles;
+    if (boundary_only) {
+        const mpm::TileRange r = s->tile_range();
+        const int columns = std::min(s->tiled.tiles_x, (r.always_lo + 1) + std::max(0, s->tiled.tiles_x - std::max(r.always_hi, r.always_lo + 1)));
+        tile_blocks = (unsigned)(columns * s->tiled.tiles_y * s->tiled.tiles_z);
+    }
     if (s->dirty)
-        hipExtLaunchKernelGGL(mpm::update_grid_tiles_kernel, dim3(s->tiled.n_tiles), dim3(256), 0, s->stream, t.start,
+        hipExtLaunchKernelGGL(mpm::update_grid_tiles_kernel, dim3(tile_blocks), dim3(256), 0, s->stream, t.start,
                               t.stop, 0, s->cell, s->mass_i, s->mass_of_cellf, s->cellf, s->dirty,
                               boundary_only ? -1 : (s->mass_bit(s->mass_i) | s->mass_bit(s->mass_of_cellf)),
                               mpm::tile_dims(s->tiled), s->params, s->tile_range());
@@ -1469,10 +1476,28 @@ static int slab_step_enter(flowmpm_sim *s, int phase, const char *name)
     return FLOWMPM_OK;
 }
 
-static int halo_side(flowmpm_sim *s, bool add, int32_t side, uint32_t mask, const void *buffer)
+// Packs (add = false) or merges (add = true) the halo pairs of both sides in one launch; a null buffer
+// means no neighbour on that side.  A thin slab's two pairs overlap (slab_nx < 2 cannot be created, at
+// slab_nx = 2 they are disjoint), so the two sides of one launch never touch the same cell.
+static int halo_sides(flowmpm_sim *s, bool add, uint32_t mask, const void *low, const void *high)
 {
-    if (!buffer) return FLOWMPM_OK;          // no neighbour on that side
-    return add ? flowmpm_halo_add(s, side, mask, buffer) : flowmpm_halo_pack(s, side, mask, const_cast<void *>(buffer));
+    if (!low && !high) return FLOWMPM_OK;
+    long long first, cells;
+    int k;
+    int rc = halo_pair(s, FLOWMPM_SIDE_LOW, mask, &first, &cells, &k);
+    if (rc) return rc;
+    mpm::HaloSides h{};
+    h.first[0] = first;
+    h.buf[0] = static_cast<int *>(const_cast<void *>(low));
+    if ((rc = halo_pair(s, FLOWMPM_SIDE_HIGH, mask, &first, &cells, &k))) return rc;
+    h.first[1] = first;
+    h.buf[1] = static_cast<int *>(const_cast<void *>(high));
+    const dim3 grid(blocks_for(cells, 256), 2);
+    if (add)
+        hipLaunchKernelGGL(mpm::halo_add_sides_kernel, grid, dim3(256), 0, s->stream, s->cell, s->mass_i, h, cells, mask & 0xFu, k);
+    else
+        hipLaunchKernelGGL(mpm::halo_pack_sides_kernel, grid, dim3(256), 0, s->stream, s->cell, s->mass_i, h, cells, mask & 0xFu, k);
+    return launch_check(s, add ? "halo_add" : "halo_pack");
 }
 
 int flowmpm_slab_step_begin(flowmpm_sim *s)
@@ -1496,8 +1521,7 @@ int flowmpm_slab_step_pack_mass(flowmpm_sim *s, void *send_low, void *send_high)
     if (rc) return rc;
     s->slab_phase = 0;
     if ((rc = stage_p2g_mass_arrivals(s))) return rc;
-    if ((rc = halo_side(s, false, FLOWMPM_SIDE_LOW, FLOWMPM_COMP_MASS, send_low))) return rc;
-    if ((rc = halo_side(s, false, FLOWMPM_SIDE_HIGH, FLOWMPM_COMP_MASS, send_high))) return rc;
+    if ((rc = halo_sides(s, false, FLOWMPM_COMP_MASS, send_low, send_high))) return rc;
     s->slab_phase = 2;
     return FLOWMPM_OK;
 }
@@ -1520,11 +1544,9 @@ int flowmpm_slab_step_boundary(flowmpm_sim *s, const void *recv_low, const void 
     int rc = slab_step_enter(s, 3, "flowmpm_slab_step_boundary");
     if (rc) return rc;
     s->slab_phase = 0;
-    if ((rc = halo_side(s, true, FLOWMPM_SIDE_LOW, FLOWMPM_COMP_MASS, recv_low))) return rc;
-    if ((rc = halo_side(s, true, FLOWMPM_SIDE_HIGH, FLOWMPM_COMP_MASS, recv_high))) return rc;
+    if ((rc = halo_sides(s, true, FLOWMPM_COMP_MASS, recv_low, recv_high))) return rc;
     if ((rc = stage_p2g_pass(s, true, false, 2))) return rc;
-    if ((rc = halo_side(s, false, FLOWMPM_SIDE_LOW, FLOWMPM_COMP_MOMENTUM, send_low))) return rc;
-    if ((rc = halo_side(s, false, FLOWMPM_SIDE_HIGH, FLOWMPM_COMP_MOMENTUM, send_high))) return rc;
+    if ((rc = halo_sides(s, false, FLOWMPM_COMP_MOMENTUM, send_low, send_high))) return rc;
     s->slab_phase = 4;
     return FLOWMPM_OK;
 }
@@ -1548,8 +1570,7 @@ int flowmpm_slab_step_end(flowmpm_sim *s, const void *recv_low, const void *recv
     int rc = slab_step_enter(s, 5, "flowmpm_slab_step_end");
     if (rc) return rc;
     s->slab_phase = 0;
-    if ((rc = halo_side(s, true, FLOWMPM_SIDE_LOW, FLOWMPM_COMP_MOMENTUM, recv_low))) return rc;
-    if ((rc = halo_side(s, true, FLOWMPM_SIDE_HIGH, FLOWMPM_COMP_MOMENTUM, recv_high))) return rc;
+    if ((rc = halo_sides(s, true, FLOWMPM_COMP_MOMENTUM, recv_low, recv_high))) return rc;
     if (recv_low || recv_high) {
         if ((rc = stage_update_grid(s, true))) return rc;
     }
@@ -1648,3 +1669,5 @@ int flowmpm_insert_arrivals(flowmpm_sim *s, const void *dev_in, int64_t count)
 }
 
 }  // extern "C"
+
+#include "slab_group.h"

@@ -354,6 +354,20 @@ gather_field_kernel(StoreSel ss, long long count, int first_slot, int width, flo
     for (int k = 0; k < width; k++) out[row * width + k] = st.slot(first_slot + k)[j];
 }
 
+// One per-particle field of slots [first, first + rows) in slot order, with the particles' ids beside it
+// (a slab's share of a field; the host of a slab group puts the shares in id order).
+__global__ void __launch_bounds__(256)
+gather_field_slots_kernel(StoreSel ss, long long first, long long rows, int first_slot, int width,
+                          float *__restrict__ out, int *__restrict__ ids_out)
+{
+    const Store st = ss.pick();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const long long j = first + i;
+    for (int k = 0; k < width; k++) out[i * width + k] = st.slot(first_slot + k)[j];
+    ids_out[i] = st.ids()[j];
+}
+
 // Halo merge of the slab decomposition: dst.comp += src.comp (wrapping i32).
 __global__ void __launch_bounds__(256)
 plane_add_kernel(int4 *__restrict__ dst, int *__restrict__ dst_mass, const int4 *__restrict__ src,
@@ -406,6 +420,48 @@ halo_add_kernel(int4 *__restrict__ dst, int *__restrict__ dst_mass, const int *_
         dst[i] = d;
     }
     if (mask & 8u) dst_mass[i] = (int)((unsigned)dst_mass[i] + (unsigned)*p);
+}
+
+// Both sides of a slab in one launch (blockIdx.y = side): a side without a neighbour has a null buffer.
+struct HaloSides {
+    long long first[2];      // first cell of the side's plane pair
+    int *buf[2];             // packed words of that side (pack: destination, add: source)
+};
+
+__global__ void __launch_bounds__(256)
+halo_pack_sides_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass, HaloSides h, long long cells,
+                       unsigned mask, int k)
+{
+    const int side = blockIdx.y;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!h.buf[side] || i >= cells) return;
+    int *o = h.buf[side] + i * k;
+    const long long c = h.first[side] + i;
+    if (mask & 7u) {
+        int4 v = cell[c];
+        if (mask & 1u) *o++ = v.x;
+        if (mask & 2u) *o++ = v.y;
+        if (mask & 4u) *o++ = v.z;
+    }
+    if (mask & 8u) *o = mass[c];
+}
+
+__global__ void __launch_bounds__(256)
+halo_add_sides_kernel(int4 *__restrict__ cell, int *__restrict__ mass, HaloSides h, long long cells, unsigned mask, int k)
+{
+    const int side = blockIdx.y;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!h.buf[side] || i >= cells) return;
+    const int *p = h.buf[side] + i * k;
+    const long long c = h.first[side] + i;
+    if (mask & 7u) {
+        int4 d = cell[c];
+        if (mask & 1u) d.x = (int)((unsigned)d.x + (unsigned)*p++);
+        if (mask & 2u) d.y = (int)((unsigned)d.y + (unsigned)*p++);
+        if (mask & 4u) d.z = (int)((unsigned)d.z + (unsigned)*p++);
+        cell[c] = d;
+    }
+    if (mask & 8u) mass[c] = (int)((unsigned)mass[c] + (unsigned)*p);
 }
 
 // 64-bit sums of the four fixed-point components over `cells` consecutive cells (conservation

@@ -1526,8 +1526,15 @@ update_grid_tiles_kernel(const int4 *__restrict__ cell, const int *__restrict__ 
                          const int *__restrict__ mass_of_cellf, float4 *__restrict__ cellf,
                          const int *__restrict__ dirty, int bits, TileDims td, Params P, TileRange r)
 {
-    // bits < 0: the always-visited (boundary) tiles only
-    const int t = blockIdx.x;
+    // bits < 0: the always-visited (boundary) tiles only, and the launch holds just their columns -- block b
+    // is tile (tx, b mod (tiles_y tiles_z)) with tx running over 0 .. always_lo, then the columns from always_hi on
+    int t = blockIdx.x;
+    if (bits < 0) {
+        const int per_column = td.tiles_y * td.tiles_z, column = t / per_column;
+        const int hi_first = max(r.always_hi, r.always_lo + 1);      // (a thin slab: every column is a boundary column)
+        const int tx = column <= r.always_lo ? column : hi_first + (column - r.always_lo - 1);
+        t = tx * per_column + (t - column * per_column);
+    }
     if (!(tile_always(t, td, r) || (bits >= 0 && (dirty[t] & bits)))) return;
     for (int k = threadIdx.x; k < kTX * kTY * kTZ; k += 256) {
         int lx, y, z;

@@ -63,9 +63,21 @@ class Handle:
                     continue          # such handles never ride
                 self.set_option(option, int(value))
 
+    @classmethod
+    def borrowed(cls, pointer, grid, max_particles, slab):
+        """A wrapper of a flowmpm_sim somebody else owns (a slab of a flowmpm_slab_group): close() leaves
+        it alone."""
+        self = cls.__new__(cls)
+        self.L = _lib.load()
+        self._h = ctypes.c_void_p(pointer)
+        self._borrowed = True
+        self.grid, self.max_particles, self.slab = tuple(grid), int(max_particles), slab
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self.L.flowmpm_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self.L.flowmpm_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -297,6 +309,120 @@ class Handle:
 
     def insert_arrivals(self, dev_in, count):
         self._chk(self.L.flowmpm_insert_arrivals(self._h, ctypes.c_void_p(dev_in), int(count)))
+
+
+class SlabGroup:
+    """flowmpm_slab_group: a decomposed domain behind one object, all slabs driven by this thread (on
+    one device, or one slab per device over RCCL).  Mirrors Handle where the calls exist for a group."""
+
+    def __init__(self, grid, plane_starts, max_particles, devices=None, rebin_interval=64):
+        self.L = _lib.load()
+        self.grid = tuple(int(g) for g in grid)
+        self.plane_starts = [int(x) for x in plane_starts]
+        self.world = len(self.plane_starts) - 1
+        caps = list(max_particles) if hasattr(max_particles, "__len__") else [int(max_particles)] * self.world
+        cfg = _lib.Config()
+        cfg.grid_x, cfg.grid_y, cfg.grid_z = self.grid
+        cfg.algorithm, cfg.rebin_interval = _lib.ALGO_TILED, int(rebin_interval)
+        cfg.device = int(devices[0]) if devices else 0
+        starts = (ctypes.c_int32 * (self.world + 1))(*self.plane_starts)
+        devs = (ctypes.c_int32 * self.world)(*[int(d) for d in devices]) if devices else None
+        cap = (ctypes.c_int64 * self.world)(*[int(c) for c in caps])
+        self._g = ctypes.c_void_p()
+        _lib.check_group(None, self.L.flowmpm_slab_group_create(ctypes.byref(cfg), starts, self.world, devs, cap,
+                                                                ctypes.byref(self._g)))
+        self.handles = []
+        for r in range(self.world):
+            h = ctypes.c_void_p()
+            self._chk(self.L.flowmpm_slab_group_slab(self._g, r, ctypes.byref(h)))
+            self.handles.append(Handle.borrowed(h.value, self.grid, caps[r],
+                                                (self.plane_starts[r], self.plane_starts[r + 1] - self.plane_starts[r])))
+
+    def _chk(self, code):
+        _lib.check_group(self._g, code)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self.L.flowmpm_slab_group_destroy(self._g)
+            self._g = None
+            self.handles = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def uses_rccl(self):
+        n, rccl = ctypes.c_int32(), ctypes.c_int32()
+        self._chk(self.L.flowmpm_slab_group_size(self._g, ctypes.byref(n), ctypes.byref(rccl)))
+        return bool(rccl.value)
+
+    def upload_particles(self, records):
+        rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, _lib.PARTICLE_STRIDE)
+        self._chk(self.L.flowmpm_slab_group_upload(self._g, _fp(rec), rec.shape[0]))
+
+    def generate_particles(self, scene, count, seed=0xF10E5EED, fill=0.25):
+        self._chk(self.L.flowmpm_slab_group_generate(self._g, int(scene), int(seed) & 0xFFFFFFFF, int(count), float(fill)))
+
+    def set_uniforms(self, **kw):
+        u = _lib.Uniforms()
+        d = dict(dt=0.1, stiffness=3.0, rest_density=2.5, dynamic_viscosity=0.1, noise=1.0, time=0.0,
+                 mouse_ray_direction=(0.0, 0.0, 0.0), mouse_ray_origin=(0.0, 0.0, 0.0), mouse_force=(0.0, 0.0, 0.0),
+                 cursor_interaction=0, hide_percentage=0.0, grid_mode=0, front_gravity_mode=0)
+        d.update(kw)
+        for name in ("dt", "stiffness", "rest_density", "dynamic_viscosity", "noise", "time", "hide_percentage"):
+            setattr(u, name, d[name])
+        u.mouse_ray_direction[:] = d["mouse_ray_direction"]
+        u.mouse_ray_origin[:] = d["mouse_ray_origin"]
+        u.mouse_force[:] = d["mouse_force"]
+        u.cursor_interaction, u.grid_mode, u.front_gravity_mode = (int(d["cursor_interaction"]), int(d["grid_mode"]),
+                                                                   int(d["front_gravity_mode"]))
+        self._chk(self.L.flowmpm_slab_group_set_uniforms(self._g, ctypes.byref(u)))
+
+    def set_mode_uniforms(self, modes):
+        self._chk(self.L.flowmpm_slab_group_set_mode_uniforms(self._g, ctypes.byref(modes)))
+
+    def step(self, n_steps=1, dtime=0.0):
+        self._chk(self.L.flowmpm_slab_group_step(self._g, int(n_steps), float(dtime)))
+
+    def synchronize(self):
+        self._chk(self.L.flowmpm_slab_group_synchronize(self._g))
+
+    def num_particles(self):
+        total = ctypes.c_int64()
+        per = np.zeros(self.world, dtype=np.int64)
+        self._chk(self.L.flowmpm_slab_group_get_num_particles(self._g, ctypes.byref(total),
+                                                              per.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        return total.value, per
+
+    def download_particles(self):
+        total, _ = self.num_particles()
+        rec = np.zeros((max(total, 1), _lib.PARTICLE_STRIDE), dtype=np.float32)
+        count = ctypes.c_int64()
+        self._chk(self.L.flowmpm_slab_group_download_particles(self._g, _fp(rec), rec.shape[0], ctypes.byref(count)))
+        return rec[:count.value]
+
+    def download_field(self, field):
+        total, _ = self.num_particles()
+        out = np.zeros((max(total, 1), _lib.FIELD_WIDTH[field]), dtype=np.float32)
+        self._chk(self.L.flowmpm_slab_group_download_field(self._g, int(field), _fp(out), out.shape[0]))
+        return out[:total]
+
+    def conservation(self):
+        out = np.zeros(5, dtype=np.int64)
+        self._chk(self.L.flowmpm_slab_group_conservation(self._g, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        return out
+
+    def migration_stats(self):
+        moved, hop = ctypes.c_int64(), ctypes.c_int32()
+        self._chk(self.L.flowmpm_slab_group_migration_stats(self._g, ctypes.byref(moved), ctypes.byref(hop)))
+        return moved.value, hop.value
+
+
+def rccl_selftest(device=0, words=1 << 16):
+    """flowmpm_rccl_selftest: a world-of-one RCCL communicator sends a buffer to itself."""
+    _lib.check(None, _lib.load().flowmpm_rccl_selftest(int(device), int(words)))
 
 
 class Vector3:

@@ -254,6 +254,7 @@ class SlabSimulation:
         self._pending_counts = None
         self._pending_matrix = None
         self._count_bufs = None
+        self._inbox = {}            # peer -> receive buffer for its migrating particles
         # RCCL on device tensors: the count exchange starts right after the classification
         # (FLOWMPM_SLAB_EARLY_COUNTS=0 keeps it where the counts are needed, for A/B runs)
         self.early_counts = (self.transport is not None and not self.transport.stage and backend is None
@@ -447,12 +448,21 @@ class SlabSimulation:
                 sends.append((packed[int(offs[peer]):int(offs[peer + 1])], peer))
             k = int(matrix[peer, self.rank])
             if k:
-                buf = b.new_record_buffer(k)
+                buf = self._inbox_for(peer, k)
                 inbox.append(buf)
                 recvs.append((buf, peer))
         self.transport.exchange(sends, recvs)
         for buf in inbox:
             b.insert_arrivals(buf)
+
+    def _inbox_for(self, peer, count):
+        """The first `count` records of the receive buffer kept for `peer`: allocated once with headroom (a
+        slab's flow through a cut changes by a few per cent from step to step), so a step allocates nothing."""
+        held = self._inbox.get(peer)
+        if held is None or held.shape[0] < count:
+            held = self.backend.new_record_buffer(max(4096, 2 * count))
+            self._inbox[peer] = held
+        return held[:count]
 
     def _check_capacities(self, matrix):
         """Every rank holds the whole count matrix, so every rank can see whether ANY rank is about to

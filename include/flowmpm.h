@@ -259,7 +259,7 @@ int flowmpm_set_mode_uniforms(flowmpm_sim *sim, const flowmpm_mode_uniforms *m);
  *   launch of its own, 0 the standalone two-launch re-bin (what flowmpm_run_kernel and slab handles
  *   always use).  The flowmpm_slab_step_* sequence of a slab handle rides in form 2 (or 0).
  * DRIFT_DIVISOR: the device re-bins when the particles outside their tile's arena, summed over the steps
- *   since the last re-bin, exceed particles / divisor (default 8192 riding, 2048 riding on a slab, 256
+ *   since the last re-bin, exceed particles / divisor (default 8192 riding, 512 riding on a slab, 256
  *   standalone, 48 standalone on a slab;
  *   0 leaves only rebin_interval).
  * CHUNK: most particles per work item (256 .. 4096, default 4096).  SPARSE_TILE: tiles with fewer
@@ -431,6 +431,49 @@ int flowmpm_slab_step_boundary(flowmpm_sim *sim, const void *recv_low, const voi
 int flowmpm_slab_step_grid(flowmpm_sim *sim);
 int flowmpm_slab_step_end(flowmpm_sim *sim, const void *recv_low, const void *recv_high,
                           const int32_t *plane_starts, int32_t n_ranks, void *dev_counts);
+
+/* ---- Slab groups: a decomposed domain behind ONE object, driven by one host thread.  The reference's
+ * caller is a single-threaded JavaScript program (src/app.js:72-80 creates the simulator, :156 awaits its
+ * update once per frame); a host in that language reaches several GPUs through a group: it owns one
+ * slab handle per x-slab (plane_starts[0 .. n_slabs], as in flowmpm_extract_leavers), steps them in
+ * lock-step with the flowmpm_slab_step_* sequence and moves halo pairs and migrating particles itself.
+ * devices[r] (NULL: base->device for all) places slab r.  All slabs on ONE device: one stream, a slab's
+ * packed halo pair is merged by its neighbour where it lies, leavers are inserted straight from the
+ * sender's buffer.  Every slab on a device of its OWN: RCCL (ncclCommInitAll over the devices, grouped
+ * ncclSend / ncclRecv on a communication stream per device, ordered against the compute stream with
+ * events, so the exchanges are in flight under the interior work items); librccl.so is loaded when such
+ * a group is created.  Any other placement is FLOWMPM_ERR_INVALID.  base supplies grid, algorithm
+ * (FLOWMPM_ALGO_TILED) and rebin_interval; max_particles[r] is slab r's capacity.  Results equal the
+ * single domain's bit for bit for any number of slabs. ---- */
+typedef struct flowmpm_slab_group flowmpm_slab_group;
+int flowmpm_slab_group_create(const flowmpm_config *base, const int32_t *plane_starts, int32_t n_slabs,
+                              const int32_t *devices, const int64_t *max_particles, flowmpm_slab_group **out);
+int flowmpm_slab_group_destroy(flowmpm_slab_group *group);
+const char *flowmpm_slab_group_last_error(const flowmpm_slab_group *group);
+int flowmpm_slab_group_size(flowmpm_slab_group *group, int32_t *n_slabs, int32_t *uses_rccl);
+/* The r-th slab handle, owned by the group (for timings, per-slab read-backs, options). */
+int flowmpm_slab_group_slab(flowmpm_slab_group *group, int32_t r, flowmpm_sim **out);
+/* flowmpm_upload_particles / flowmpm_generate_particles for the whole domain: every record goes to the
+ * slab that owns floor(position.x); record i is particle id i. */
+int flowmpm_slab_group_upload(flowmpm_slab_group *group, const float *aos, int64_t count);
+int flowmpm_slab_group_generate(flowmpm_slab_group *group, int32_t scene, uint32_t seed, int64_t count, double fill);
+int flowmpm_slab_group_set_uniforms(flowmpm_slab_group *group, const flowmpm_uniforms *u);
+int flowmpm_slab_group_set_mode_uniforms(flowmpm_slab_group *group, const flowmpm_mode_uniforms *m);
+/* flowmpm_step over the decomposed domain (SIM:2538-2539).  Asynchronous except for one wait per step
+ * on the migration counts of the step before, which have long arrived when it is reached. */
+int flowmpm_slab_group_step(flowmpm_slab_group *group, int32_t n_steps, double dtime);
+int flowmpm_slab_group_synchronize(flowmpm_slab_group *group);
+int flowmpm_slab_group_get_num_particles(flowmpm_slab_group *group, int64_t *total, int64_t *per_slab);
+/* Read-backs in particle-id order, as from a single-domain handle. */
+int flowmpm_slab_group_download_particles(flowmpm_slab_group *group, float *aos, int64_t capacity, int64_t *count);
+int flowmpm_slab_group_download_field(flowmpm_slab_group *group, int32_t field, float *out, int64_t capacity);
+/* flowmpm_grid_sums summed over the slabs, then the particle count: sums[0..2] momentum, [3] mass, [4] particles. */
+int flowmpm_slab_group_conservation(flowmpm_slab_group *group, int64_t sums[5]);
+/* Particles handed from slab to slab so far, and the farthest destination in slabs (1 = a neighbour). */
+int flowmpm_slab_group_migration_stats(flowmpm_slab_group *group, int64_t *migrated, int32_t *max_hop);
+/* RCCL in a world of one on `device`: a communicator, `words` 32-bit words sent to itself inside one group
+ * call, compared on the host.  What a host runs before it creates a group over several devices. */
+int flowmpm_rccl_selftest(int32_t device, int64_t words);
 
 #ifdef __cplusplus
 }

@@ -419,3 +419,65 @@ def test_slab_step_calls_out_of_order_are_refused():
     with pytest.raises(_lib.FlowMpmError):
         single.slab_step_begin()
     single.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("starts", [[0, 37, 48, 57, 66, 74, 83, 95, 142], [0, 142], [0, 70, 142]], ids=["eight", "one", "two"])
+def test_native_slab_group_matches_single_domain(oracle_binding, starts):
+    """flowmpm_slab_group: the whole decomposed step, migration and halo merges inside the library, all
+    slabs on the one GPU -- against the single-domain oracle, bit for bit, with read-backs in id order."""
+    from flow_amd import SlabGroup
+
+    grid, n, steps, dt = (142, 16, 24), 40000, 9, 1.0
+    rec = moving_particles(n, grid, seed=53, vel=3.0)
+    group = SlabGroup(grid, starts, n, rebin_interval=2)
+    assert not group.uses_rccl()
+    group.upload_particles(rec)
+    assert group.num_particles()[0] == n
+    for k in range(steps):
+        group.set_uniforms(**dict(DEFAULT_UNIFORMS, dt=dt, time=0.25 * k))
+        group.step(1, 0.0)
+    want = rec.copy()
+    orc = oracle_binding.Oracle(grid, threads=8)
+    for k in range(steps):
+        orc.step(want, oracle_binding.make_uniforms(grid, n, **dict(DEFAULT_UNIFORMS, dt=dt, time=0.25 * k)))
+    assert_bits_equal(group.download_particles(), want, "particles in id order")
+    assert_bits_equal(group.download_field(_lib.FIELD_POSITION), want[:, 0:3], "positions in id order")
+    assert_bits_equal(group.download_field(_lib.FIELD_DENSITY), want[:, 3:4], "densities in id order")
+    totals = group.conservation()
+    assert np.array_equal(totals[:4], orc.cell.astype(np.int64).sum(axis=0)) and int(totals[4]) == n
+    per = grid[1] * grid[2]
+    for r, h in enumerate(group.handles):
+        x0, x1 = starts[r], starts[r + 1]
+        assert np.array_equal(h.download_grid_i32()[per:(x1 - x0 + 1) * per], orc.cell[x0 * per:x1 * per]), "slab %d grid" % r
+    moved, hop = group.migration_stats()
+    if len(starts) > 2:
+        assert moved > 0 and (hop >= 2 or len(starts) == 3)
+    # several steps in one call with the clock advancing, as flowmpm_step does
+    group.set_uniforms(**dict(DEFAULT_UNIFORMS, dt=0.1, time=1.0))
+    group.step(4, 1.0 / 60)
+    for k in range(4):
+        orc.step(want, oracle_binding.make_uniforms(grid, n, **dict(DEFAULT_UNIFORMS, dt=0.1, time=np.float32(1.0 + k / 60))))
+    assert_bits_equal(group.download_particles(), want, "particles after a multi-step call")
+    group.close()
+
+
+@pytest.mark.gpu
+def test_native_slab_group_generates_its_scene_and_refuses_bad_placements():
+    from flow_amd import SlabGroup
+    grid, n = (64, 24, 24), 50000
+    group = SlabGroup(grid, [0, 30, 64], n)
+    group.generate_particles(_lib.SCENE_ELLIPSOID, n, seed=9)
+    from flow_amd.particles import reference_scene
+    assert_bits_equal(group.download_particles(), reference_scene(n, grid, seed=9), "generated scene through the group")
+    group.close()
+    with pytest.raises(_lib.FlowMpmError):
+        SlabGroup(grid, [0, 30, 63], n)                     # does not end at grid_x
+    with pytest.raises(_lib.FlowMpmError):
+        SlabGroup(grid, [0, 20, 40, 64], n, devices=[0, 0, 1])     # neither one device nor one each
+
+
+@pytest.mark.gpu
+def test_rccl_world_of_one_sends_to_itself():
+    from flow_amd.simulator import rccl_selftest
+    rccl_selftest(0, 1 << 18)
