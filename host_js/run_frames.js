@@ -18,7 +18,9 @@ const { MlsMpmSimulator, Conf } = require('./index');
     conf.particles = Number(particles);
     conf.updateParams();
     let now = 50000;
-    const sim = new MlsMpmSimulator(null, { conf, rebinInterval: 2, clock: () => now });
+    // FLOW_SLABS='[0,60,128]': the same run as a slab group (one process, all slabs on the one GPU)
+    const slabs = process.env.FLOW_SLABS ? { planeStarts: JSON.parse(process.env.FLOW_SLABS) } : null;
+    const sim = new MlsMpmSimulator(null, { conf, rebinInterval: 2, clock: () => now, slabs });
     await sim.init();
     fs.writeFileSync(out + '.init', Buffer.from(sim.particleBuffer.floatArray.buffer));
     if (schedule) {
@@ -48,4 +50,5 @@ const { MlsMpmSimulator, Conf } = require('./index');
     fs.writeFileSync(out, Buffer.from(rec.buffer));
     const pos = sim.getPositions();
     fs.writeFileSync(out + '.pos', Buffer.from(pos.buffer));
+    if (slabs) fs.writeFileSync(out + '.group.json', JSON.stringify(sim.domain.info()));
 })().catch((e) => { console.error(e); process.exit(1); });

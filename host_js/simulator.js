@@ -21,6 +21,55 @@ function native() {
 const FIELD = { position: 0, velocity: 1, density: 2, color: 3, direction: 4, mass: 5 };
 const uniform = (value) => ({ value });
 
+// What the simulator asks of the device side: one handle on one GPU, or (option `slabs`) a slab group --
+// the same domain cut into x-slabs, all driven by this thread through one object of the library, on one
+// device or one slab per device over RCCL.  Results are bit-identical either way.
+class SingleDomain {
+    constructor(grid, maxParticles, o) {
+        this.handle = native().create({ gridX: grid[0], gridY: grid[1], gridZ: grid[2], maxParticles, device: o.device,
+            algorithm: o.algorithm, rebinInterval: o.rebinInterval });
+    }
+    upload(floatArray, count) { native().uploadParticles(this.handle, floatArray, count); }
+    setNumParticles(n) { native().setNumParticles(this.handle, n); }
+    setUniforms(u) { native().setUniforms(this.handle, u); }
+    setModeUniforms(buf) { native().setModeUniforms(this.handle, buf); }
+    step(n, dtime) { native().step(this.handle, n, dtime); }
+    field(id, out) { native().downloadField(this.handle, id, out); }
+    particles(out) { return native().downloadParticles(this.handle, out); }
+    synchronize() { native().synchronize(this.handle); }
+}
+
+class SlabDomain {
+    // slabs: {planeStarts: [0, ..., gridX], devices?: [...], maxParticlesPerSlab?: n}
+    constructor(grid, maxParticles, o) {
+        const starts = o.slabs.planeStarts, n = starts.length - 1;
+        const cap = o.slabs.maxParticlesPerSlab || maxParticles;
+        this.floatArray = null;
+        this.live = -1;
+        this.stepped = false;
+        this.group = native().groupCreate({ gridX: grid[0], gridY: grid[1], gridZ: grid[2], planeStarts: starts,
+            maxParticles: new Array(n).fill(cap), devices: o.slabs.devices, rebinInterval: o.rebinInterval });
+    }
+    // the group holds the LIVE particles only: the records beyond the live count stay in the host array
+    upload(floatArray) { this.floatArray = floatArray; }
+    setNumParticles(n) {
+        if (this.stepped) throw new Error('the particle count of a decomposed domain is fixed once it has stepped');
+        native().groupUpload(this.group, this.floatArray, n);
+        this.live = n;
+    }
+    setUniforms(u) { native().groupSetUniforms(this.group, u); }
+    setModeUniforms(buf) { native().groupSetModeUniforms(this.group, buf); }
+    step(n, dtime) { this.stepped = true; native().groupStep(this.group, n, dtime); }
+    field(id, out) { native().groupDownloadField(this.group, id, out); }
+    particles(out) {
+        out.set(this.floatArray);
+        native().groupDownloadParticles(this.group, out.subarray(0, this.live * 28));
+        return this.floatArray.length / 28;
+    }
+    synchronize() { native().groupSynchronize(this.group); }
+    info() { return native().groupInfo(this.group); }
+}
+
 class MlsMpmSimulator {
     constructor(renderer, options) {
         const o = options || {};
@@ -37,7 +86,8 @@ class MlsMpmSimulator {
         this.mousePos = new Vector3();
         this.mousePosArray = [];
         this.particleBuffer = null;
-        this.handle = null;
+        this.domain = null;                      // SingleDomain or SlabDomain
+        this.slabs = o.slabs || null;
         this.clock = o.clock || null;            // stands in for Date.now() (SIM:1827, 2428)
         this.modes = null;
     }
@@ -58,10 +108,12 @@ class MlsMpmSimulator {
         u.mouseForce = uniform(new Vector3()); u.cursorInteraction = uniform(0); u.hidePercentage = uniform(0.0);
         u.time = uniform(0.0);                   // three.js TSL `time` node (SIM:22, 1318)
         this.modes = new ModeHost(u, this.clock);                         // SIM:154-254
-        this.handle = native().create({ gridX: 128, gridY: 64, gridZ: 64, maxParticles, device: this.device,
-            algorithm: this.algorithm, rebinInterval: this.rebinInterval });
-        native().uploadParticles(this.handle, this.particleBuffer.floatArray, maxParticles);
+        const o = { device: this.device, algorithm: this.algorithm, rebinInterval: this.rebinInterval, slabs: this.slabs };
+        this.domain = new (this.slabs ? SlabDomain : SingleDomain)(this.gridSize.toArray(), maxParticles, o);
+        this.domain.upload(this.particleBuffer.floatArray, maxParticles);
     }
+
+    get handle() { return this.domain ? this.domain.handle : null; }
 
     setMouseRay(origin, direction, pos) {        // SIM:1539-1546, arguments mutated as there
         origin.multiplyScalar(64);
@@ -96,7 +148,7 @@ class MlsMpmSimulator {
         if (c.particles !== this.numParticles) {                          // SIM:2513-2522
             this.numParticles = c.particles;
             u.numParticles.value = c.particles;
-            native().setNumParticles(this.handle, c.particles);
+            this.domain.setNumParticles(c.particles);
         }
         interval = Math.min(interval, 1 / 60);                            // SIM:2524-2528
         const effectiveSpeed = (u.frontGravityMode.value === 1) ? 4.0 : c.speed;
@@ -108,7 +160,7 @@ class MlsMpmSimulator {
                 .sub(this.mousePosArray[0]).divideScalar(this.mousePosArray.length);
         }
         if (c.run) {                                                      // SIM:2537-2540
-            native().setUniforms(this.handle, {
+            this.domain.setUniforms({
                 dt: u.dt.value, stiffness: u.stiffness.value, restDensity: u.restDensity.value,
                 dynamicViscosity: u.dynamicViscosity.value, noise: u.noise.value, time: u.time.value,
                 mouseRayDirection: u.mouseRayDirection.value.toArray(), mouseRayOrigin: u.mouseRayOrigin.value.toArray(),
@@ -116,8 +168,8 @@ class MlsMpmSimulator {
                 hidePercentage: u.hidePercentage.value, gridMode: u.gridMode.value,
                 frontGravityMode: u.frontGravityMode.value,
             });
-            native().setModeUniforms(this.handle, this.modes.pack());
-            native().step(this.handle, 1, 0.0);
+            this.domain.setModeUniforms(this.modes.pack());
+            this.domain.step(1, 0.0);
         }
     }
 
@@ -125,7 +177,7 @@ class MlsMpmSimulator {
     // src/mls-mpm/pointRenderer.js:17-19), as Float32Arrays in particle-id order.
     _field(name, width) {
         const out = new Float32Array(this.numParticles * width);
-        native().downloadField(this.handle, FIELD[name], out);
+        this.domain.field(FIELD[name], out);
         return out;
     }
     getPositions() { return this._field('position', 3); }
@@ -144,13 +196,13 @@ class MlsMpmSimulator {
     readAoS() {
         const b = this.particleBuffer, at = b.layout.color.offset;
         const rec = new Float32Array(b.floatArray.length);
-        native().downloadParticles(this.handle, rec);
+        this.domain.particles(rec);
         for (let i = 0; i < rec.length; i += b.structSize)
             for (let a = 0; a < 3; a++) rec[i + at + a] = b.floatArray[i + at + a];
         b.floatArray.set(rec);
         return b.floatArray;
     }
-    synchronize() { native().synchronize(this.handle); }
+    synchronize() { this.domain.synchronize(); }
 }
 
 module.exports = { MlsMpmSimulator, native, FIELD };

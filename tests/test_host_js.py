@@ -32,7 +32,9 @@ def test_addon_loads_and_exposes_the_binding():
         const m = require('./host_js');
         const names = ['create','uploadParticles','setNumParticles','setUniforms','step','synchronize',
                        'downloadParticles','downloadField','downloadGridI32','downloadGridF32','deviceCount','version',
-                       'setModeUniforms','modeUniformsSize'];
+                       'setModeUniforms','modeUniformsSize','groupCreate','groupUpload','groupGenerate','groupSetUniforms',
+                       'groupSetModeUniforms','groupStep','groupSynchronize','groupDownloadParticles','groupDownloadField',
+                       'groupInfo','groupSlabGridI32','rcclSelftest'];
         const missing = names.filter((n) => typeof m.native()[n] !== 'function');
         console.log(JSON.stringify({missing, version: m.native().version()}));
     """)
@@ -258,3 +260,40 @@ def test_js_simulator_image_modes_match_oracle(oracle_binding, tmp_path):
             orc.step_modes(want, u, m)
             k += 1
     assert_bits_equal(got[:particles, :24], want[:particles, :24], "JS host records after the image modes")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slabs", ["[0,60,128]", "[0,40,66,90,128]"], ids=["two_slabs", "four_slabs"])
+def test_js_simulator_over_a_slab_group_matches_oracle(oracle_binding, tmp_path, slabs):
+    """The JavaScript class with the option `slabs`: one Node process drives several slab handles on the one
+    GPU through flowmpm_slab_group (halo merges and particle migration inside the library), frame by frame
+    through update() -- records, getPositions() and the conservation sums equal the single-domain oracle's."""
+    out = str(tmp_path / "records.bin")
+    max_particles, particles, frames = 16384, 12000, 12
+    env = dict(os.environ, FLOW_SLABS=slabs)
+    r = subprocess.run([NODE, os.path.join(ROOT, "host_js", "run_frames.js"), out, str(max_particles),
+                        str(particles), str(frames)], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    init = np.fromfile(out + ".init", dtype=np.float32).reshape(max_particles, 28)
+    got = np.fromfile(out, dtype=np.float32).reshape(max_particles, 28)
+    grid = (128, 64, 64)
+    orc = oracle_binding.Oracle(grid, threads=4)
+    want = init.copy()
+    rest = 0.25 * max(particles / 8192, 1)
+    for f in range(frames):
+        u = oracle_binding.make_uniforms(grid, particles, dt=(1 / 60) * 6, stiffness=3.0, rest_density=rest,
+                                         dynamic_viscosity=0.1, noise=1.0, time=0.5 * f)
+        orc.step(want, u)
+    assert_bits_equal(got, want, "JS host records after %d frames over %s" % (frames, slabs))
+    pos = np.fromfile(out + ".pos", dtype=np.float32).reshape(particles, 3)
+    assert_bits_equal(pos, want[:particles, 0:3], "getPositions()")
+    with open(out + ".group.json") as f:
+        info = json.load(f)
+    assert info["slabs"] == len(json.loads(slabs)) - 1 and info["rccl"] is False and info["particles"] == particles
+    assert info["conservation"] == [int(v) for v in orc.cell.astype(np.int64).sum(axis=0)] + [particles]
+    assert sum(info["perSlab"]) == particles
+
+
+@pytest.mark.gpu
+def test_js_rccl_world_of_one():
+    _node("require('./host_js').native().rcclSelftest(0, 65536); console.log('ok');")
