@@ -57,6 +57,7 @@ EXPORTS = (
     "flowmpm_slab_group_step", "flowmpm_slab_group_synchronize", "flowmpm_slab_group_get_num_particles",
     "flowmpm_slab_group_download_particles", "flowmpm_slab_group_download_field",
     "flowmpm_slab_group_conservation", "flowmpm_slab_group_migration_stats", "flowmpm_rccl_selftest",
+    "flowmpm_set_slab", "flowmpm_slab_group_rebalance", "flowmpm_slab_group_plane_starts",
 )
 SCENE_ELLIPSOID, SCENE_DAM_BREAK = 0, 1
 OPTION_RIDE_REBINS, OPTION_DRIFT_DIVISOR, OPTION_CHUNK, OPTION_SPARSE_TILE = range(4)
@@ -71,6 +72,7 @@ class Config(ctypes.Structure):
         ("max_particles", ctypes.c_int64),
         ("stream", ctypes.c_void_p),
         ("external_stream", ctypes.c_int32),
+        ("slab_max_nx", ctypes.c_int32),
     ]
 
 
@@ -212,6 +214,9 @@ def load():
         "flowmpm_slab_group_conservation": ([vp, i64p], ctypes.c_int),
         "flowmpm_slab_group_migration_stats": ([vp, i64p, ip], ctypes.c_int),
         "flowmpm_rccl_selftest": ([i32, i64], ctypes.c_int),
+        "flowmpm_set_slab": ([vp, i32, i32], ctypes.c_int),
+        "flowmpm_slab_group_rebalance": ([vp, ctypes.c_double, ip], ctypes.c_int),
+        "flowmpm_slab_group_plane_starts": ([vp, ip], ctypes.c_int),
         "flowmpm_scene_plane_histogram": ([i32, i32, u32, i64, i64, ip, ctypes.c_double, i64p], ctypes.c_int),
     }
     for name, (argtypes, restype) in protos.items():

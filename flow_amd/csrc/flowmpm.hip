@@ -132,6 +132,7 @@ struct flowmpm_sim {
     }
     float4 *cellf = nullptr;
     long long local_cells = 0;
+    int plane_cap = 0;           // local planes the grids were allocated for (flowmpm_set_slab stays within)
     std::vector<float> shadow;   // host copy of records beyond `live` (single GPU)
 
     mpm::TiledState tiled{};     // bins, work items (FLOWMPM_ALGO_TILED)
@@ -686,6 +687,8 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         return fail(nullptr, FLOWMPM_ERR_INVALID, "slab outside the grid");
     if (c.slab_nx > 0 && c.slab_nx < 2)
         return fail(nullptr, FLOWMPM_ERR_INVALID, "a slab needs at least 2 planes");
+    if (c.slab_max_nx < 0 || c.slab_max_nx > c.grid_x || (c.slab_nx == 0 && c.slab_max_nx != 0))
+        return fail(nullptr, FLOWMPM_ERR_INVALID, "slab_max_nx must lie between 0 and grid_x (slab handles only)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -712,16 +715,18 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         }
         refresh_params(s);
         s->local_cells = (long long)s->params.local_nx * c.grid_y * c.grid_z;
-        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->cell), (size_t)s->local_cells * sizeof(int4)));
-        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->cellf), (size_t)s->local_cells * sizeof(float4)));
-        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->mass_i), (size_t)s->local_cells * sizeof(int)));
-        HIP_TRY(s, hipMemsetAsync(s->cell, 0, (size_t)s->local_cells * sizeof(int4), s->stream));
-        HIP_TRY(s, hipMemsetAsync(s->mass_i, 0, (size_t)s->local_cells * sizeof(int), s->stream));
-        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->mass_spare), (size_t)s->local_cells * sizeof(int)));
-        HIP_TRY(s, hipMemsetAsync(s->mass_spare, 0, (size_t)s->local_cells * sizeof(int), s->stream));
+        s->plane_cap = s->slab ? std::max(c.slab_nx, c.slab_max_nx) + 2 : c.grid_x;
+        const size_t cells_cap = (size_t)s->plane_cap * c.grid_y * c.grid_z;
+        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->cell), cells_cap * sizeof(int4)));
+        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->cellf), cells_cap * sizeof(float4)));
+        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->mass_i), cells_cap * sizeof(int)));
+        HIP_TRY(s, hipMemsetAsync(s->cell, 0, cells_cap * sizeof(int4), s->stream));
+        HIP_TRY(s, hipMemsetAsync(s->mass_i, 0, cells_cap * sizeof(int), s->stream));
+        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->mass_spare), cells_cap * sizeof(int)));
+        HIP_TRY(s, hipMemsetAsync(s->mass_spare, 0, cells_cap * sizeof(int), s->stream));
         s->mass_of_cellf = s->mass_i;
         s->mass_first = s->mass_i;
-        HIP_TRY(s, hipMemsetAsync(s->cellf, 0, (size_t)s->local_cells * sizeof(float4), s->stream));
+        HIP_TRY(s, hipMemsetAsync(s->cellf, 0, cells_cap * sizeof(float4), s->stream));
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->d_modes), sizeof(mpm::ModeParams)));
         HIP_TRY(s, hipMemsetAsync(s->d_modes, 0, sizeof(mpm::ModeParams), s->stream));
         int r = alloc_store(s, 0);
@@ -729,7 +734,7 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         if (c.algorithm != FLOWMPM_ALGO_SCATTER) {
             if ((r = alloc_store(s, 1))) return r;
             std::string msg;
-            if (mpm::tiled_init(s->tiled, s->params, s->capacity, s->stream, &msg))
+            if (mpm::tiled_init(s->tiled, s->params, s->capacity, s->plane_cap, s->stream, &msg))
                 return fail(s, FLOWMPM_ERR_HIP, "tiled_init: " + msg);
             s->store.cur = &s->tiled.ctl->cur;
             // A slab takes in arrivals every step, all of them outside the binning until the next re-bin:
@@ -749,8 +754,8 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
             // A slab takes in a few thousand arrivals per step, all outside the binning until the next re-bin and
             // each costing three stages of global atomics: with re-bins this cheap it re-bins every few steps.
             if (s->ride_rebins) s->drift_divisor = s->slab ? kSlabRideDivisor : 8192;
-            HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->dirty), (size_t)s->tiled.n_tiles * sizeof(int)));
-            HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
+            HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->dirty), (size_t)s->tiled.tiles_cap * sizeof(int)));
+            HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.tiles_cap * sizeof(int), s->stream));
         }
         // The leaver lists are sized once: a quarter of the slots may leave in one step before the
         // lists have to grow (growing frees device memory, which waits for the device).
@@ -1458,6 +1463,44 @@ int flowmpm_halo_add(flowmpm_sim *s, int32_t side, uint32_t comp_mask, const voi
     hipLaunchKernelGGL(mpm::halo_add_kernel, dim3(blocks_for(cells, 256)), dim3(256), 0, s->stream, s->cell + first,
                        s->mass_i + first, reinterpret_cast<const int *>(dev_src), cells, comp_mask & 0xFu, k);
     return launch_check(s, "halo_add");
+}
+
+int flowmpm_set_slab(flowmpm_sim *s, int32_t slab_x0, int32_t slab_nx)
+{
+    CHECK_SIM(s);
+    if (!s->slab) return fail(s, FLOWMPM_ERR_INVALID, "not a slab handle");
+    if (slab_nx < 2 || slab_x0 < 0 || slab_x0 + slab_nx > s->cfg.grid_x) return fail(s, FLOWMPM_ERR_INVALID, "slab outside the grid");
+    if (slab_nx + 2 > s->plane_cap) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "%d planes asked for, the handle was created for at most %d (flowmpm_config.slab_max_nx)",
+                 slab_nx, s->plane_cap - 2);
+        return fail(s, FLOWMPM_ERR_CAPACITY, buf);
+    }
+    if (s->slab_phase != 0) return fail(s, FLOWMPM_ERR_INVALID, "a slab is re-cut between steps, not inside one");
+    if (slab_x0 == s->cfg.slab_x0 && slab_nx == s->cfg.slab_nx) return FLOWMPM_OK;
+    s->cfg.slab_x0 = slab_x0;
+    s->cfg.slab_nx = slab_nx;
+    refresh_params(s);
+    s->local_cells = (long long)s->params.local_nx * s->cfg.grid_y * s->cfg.grid_z;
+    // the planes the local grids hold have changed: what they held means nothing any more
+    HIP_TRY(s, hipMemsetAsync(s->cell, 0, (size_t)s->local_cells * sizeof(int4), s->stream));
+    HIP_TRY(s, hipMemsetAsync(s->cellf, 0, (size_t)s->local_cells * sizeof(float4), s->stream));
+    HIP_TRY(s, hipMemsetAsync(s->mass_i, 0, (size_t)s->local_cells * sizeof(int), s->stream));
+    HIP_TRY(s, hipMemsetAsync(s->mass_spare, 0, (size_t)s->local_cells * sizeof(int), s->stream));
+    s->mass_of_cellf = s->mass_i;
+    if (is_tiled(s)) {
+        mpm::tiled_set_planes(s->tiled, s->params, s->params.local_nx);
+        HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.tiles_cap * sizeof(int), s->stream));
+        s->tiled.valid = false;          // the next step bins the particles under the new tiles
+        s->tiled.checked = false;
+        s->tiled.listed = -1;
+        s->tiled.scan_after_mass = false;
+    }
+    s->tiles_marked = false;
+    s->stayers_done = false;
+    s->arrivals_first = -1;
+    s->migration.classified = -1;
+    return FLOWMPM_OK;
 }
 
 // ---- one slab step in six calls (see include/flowmpm.h) -----------------------------------

@@ -6,6 +6,7 @@
 #pragma once
 
 #include <string>
+#include <vector>
 
 #include "kernels_scatter.h"
 
@@ -172,6 +173,59 @@ __global__ void export_counts_kernel(const int *__restrict__ counters, int n_ran
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n_ranks) out[r] = counters[r];
+}
+
+// Slab boundaries that give every rank about the same number of particles, from the particles-per-plane
+// histogram of the whole domain: cut at the particle quantiles, every slab at least 2 planes wide
+// (flow_amd/slab.py: plane_starts_from_histogram is the same rule).
+inline std::vector<int> balanced_plane_starts(const std::vector<int64_t> &hist, int world)
+{
+    const int gx = (int)hist.size();
+    std::vector<int64_t> cum((size_t)gx);
+    int64_t total = 0;
+    for (int x = 0; x < gx; x++) { total += hist[(size_t)x]; cum[(size_t)x] = total; }
+    std::vector<int> starts{0};
+    for (int r = 1; r < world; r++) {
+        // first plane whose cumulative count reaches total * r / world (double, as numpy's searchsorted sees it)
+        const double want = (double)total * r / world;
+        int cut = 0;
+        while (cut < gx && (double)cum[(size_t)cut] < want) cut++;
+        cut += 1;
+        cut = std::max(cut, starts.back() + 2);
+        cut = std::min(cut, gx - 2 * (world - r));
+        starts.push_back(cut);
+    }
+    starts.push_back(gx);
+    return starts;
+}
+
+// The balanced cut, approached from the current one: boundary r moves toward its balanced place only as
+// far as at most `budget` particles change hands through it, and no slab becomes wider than max_nx[r] or
+// narrower than 2 planes (flow_amd/slab.py: limited_plane_starts is the same rule).
+inline std::vector<int> limited_plane_starts(const std::vector<int64_t> &hist, const std::vector<int> &current,
+                                             const std::vector<int> &max_nx, int64_t budget)
+{
+    const int world = (int)current.size() - 1;
+    const std::vector<int> want = balanced_plane_starts(hist, world);
+    std::vector<int> next = current;
+    for (int r = 1; r < world; r++) {
+        int cut = current[(size_t)r];
+        const int dir = want[(size_t)r] > cut ? 1 : -1;
+        int64_t moved = 0;
+        while (cut != want[(size_t)r]) {
+            const int plane = dir > 0 ? cut : cut - 1;          // the plane that changes hands
+            if (moved > 0 && moved + hist[(size_t)plane] > budget) break;      // (one plane always may move)
+            moved += hist[(size_t)plane];
+            cut += dir;
+        }
+        next[(size_t)r] = cut;
+    }
+    // widths: at least 2 planes, at most what the handle was created for (left to right, then right to left)
+    for (int r = 1; r < world; r++) next[(size_t)r] = std::max(next[(size_t)r], next[(size_t)r - 1] + 2);
+    for (int r = world - 1; r >= 1; r--) next[(size_t)r] = std::min(next[(size_t)r], next[(size_t)r + 1] - 2);
+    for (int r = 0; r < world; r++)
+        if (next[(size_t)r + 1] - next[(size_t)r] > max_nx[(size_t)r]) return current;      // does not fit: leave the cut alone
+    return next;
 }
 
 struct MigrationScratch {

@@ -170,6 +170,7 @@ struct TiledState {
     bool checked = false;        // the decision for the current step has been enqueued
     RebinCtl *ctl = nullptr;     // device
     int tiles_x = 0, tiles_y = 0, tiles_z = 0, n_tiles = 0;
+    int tiles_cap = 0;           // tiles the per-tile arrays were allocated for (>= n_tiles)
     long long item_cap = 0;
     int *key = nullptr;          // per slot: tile id
     int *rank = nullptr;         // per slot: position inside its tile's run
@@ -1548,12 +1549,21 @@ update_grid_tiles_kernel(const int4 *__restrict__ cell, const int *__restrict__ 
 
 inline TileDims tile_dims(const TiledState &T) { return TileDims{T.tiles_x, T.tiles_y, T.tiles_z}; }
 
-inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStream_t stream, std::string *msg)
+// The tile dimensions of a local grid of local_nx planes (a slab that is re-cut calls this again).
+inline void tiled_set_planes(TiledState &T, const Params &P, int local_nx)
 {
-    T.tiles_x = (P.local_nx + kTX - 1) / kTX;
+    T.tiles_x = (local_nx + kTX - 1) / kTX;
     T.tiles_y = (P.gy + kTY - 1) / kTY;
     T.tiles_z = (P.gz + kTZ - 1) / kTZ;
     T.n_tiles = T.tiles_x * T.tiles_y * T.tiles_z;
+}
+
+// max_local_nx: the most planes the local grid will ever hold (the per-tile arrays are sized for it).
+inline int tiled_init(TiledState &T, const Params &P, long long capacity, int max_local_nx, hipStream_t stream,
+                      std::string *msg)
+{
+    tiled_set_planes(T, P, max_local_nx);
+    T.tiles_cap = T.n_tiles;
     T.item_cap = (long long)T.n_tiles + capacity / kChunkMin + 1;
     hipError_t e;
     auto chk = [&](hipError_t err, const char *what) {
@@ -1576,6 +1586,7 @@ inline int tiled_init(TiledState &T, const Params &P, long long capacity, hipStr
     T.n_items = reinterpret_cast<int *>(reinterpret_cast<char *>(T.ctl) + offsetof(RebinCtl, n_items));
     T.valid = false;
     T.checked = false;
+    tiled_set_planes(T, P, P.local_nx);
     return 0;
 }
 

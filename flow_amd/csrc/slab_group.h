@@ -647,6 +647,49 @@ int flowmpm_slab_group_migration_stats(flowmpm_slab_group *g, int64_t *migrated,
     return FLOWMPM_OK;
 }
 
+int flowmpm_slab_group_plane_starts(flowmpm_slab_group *g, int32_t *plane_starts)
+{
+    if (!g || !plane_starts) return slabgroup::gfail(g, FLOWMPM_ERR_INVALID, "null argument");
+    for (int r = 0; r <= g->n; r++) plane_starts[r] = g->starts[r];
+    return FLOWMPM_OK;
+}
+
+int flowmpm_slab_group_rebalance(flowmpm_slab_group *g, double max_move_fraction, int32_t *changed)
+{
+    using namespace slabgroup;
+    if (!g) return gfail(nullptr, FLOWMPM_ERR_INVALID, "null group");
+    if (changed) *changed = 0;
+    if (!(max_move_fraction > 0.0 && max_move_fraction <= 1.0)) return gfail(g, FLOWMPM_ERR_INVALID, "0 < max_move_fraction <= 1");
+    if (g->n < 2) return FLOWMPM_OK;
+    int rc = migrate(g);                  // every particle sits on its owner
+    if (rc) return rc;
+    const int gx = g->m[0].sim->cfg.grid_x;
+    std::vector<int64_t> hist((size_t)gx, 0), part((size_t)gx);
+    int64_t total = 0;
+    for (int r = 0; r < g->n; r++) {
+        GROUP_SIM(g, r, flowmpm_plane_histogram(g->m[r].sim, part.data(), gx));
+        for (int x = 0; x < gx; x++) { hist[(size_t)x] += part[(size_t)x]; total += part[(size_t)x]; }
+    }
+    if (total == 0) return FLOWMPM_OK;
+    std::vector<int> max_nx((size_t)g->n);
+    for (int r = 0; r < g->n; r++) max_nx[(size_t)r] = g->m[r].sim->plane_cap - 2;
+    std::vector<int> next = mpm::limited_plane_starts(hist, g->starts, max_nx, (int64_t)(max_move_fraction * (double)total / g->n));
+    if (next == g->starts) return FLOWMPM_OK;
+    for (int r = 0; r < g->n; r++) GROUP_SIM(g, r, flowmpm_set_slab(g->m[r].sim, next[(size_t)r], next[(size_t)r + 1] - next[(size_t)r]));
+    g->starts = next;
+    // the classification under the new cut: the next step's migration moves the planes that changed hands
+    for (int r = 0; r < g->n; r++) {
+        Member &M = g->m[r];
+        GROUP_SIM(g, r, flowmpm_find_leavers(M.sim, g->starts.data(), g->n, M.d_counts));
+        GROUP_HIP(g, hipSetDevice(M.device));
+        GROUP_HIP(g, hipMemcpyAsync(M.h_counts, M.d_counts, (size_t)g->n * sizeof(long long), hipMemcpyDeviceToHost, M.sim->stream));
+        GROUP_HIP(g, hipEventRecord(M.counts_ready, M.sim->stream));
+    }
+    g->pending = true;
+    if (changed) *changed = 1;
+    return FLOWMPM_OK;
+}
+
 // RCCL in a world of one: a communicator on `device`, a buffer sent to itself inside one group call and
 // compared.  What a host checks before it creates a group over several devices.
 int flowmpm_rccl_selftest(int32_t device, int64_t words)

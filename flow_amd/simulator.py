@@ -35,7 +35,7 @@ class Handle:
     """One flowmpm_sim.  Every method maps to one C entry point."""
 
     def __init__(self, grid, max_particles, device=0, algorithm=_lib.ALGO_TILED, rebin_interval=1,
-                 slab=None, stream=None, external_stream=False):
+                 slab=None, stream=None, external_stream=False, slab_max_nx=0):
         self.L = _lib.load()
         cfg = _lib.Config()
         cfg.grid_x, cfg.grid_y, cfg.grid_z = (int(g) for g in grid)
@@ -46,6 +46,7 @@ class Handle:
         cfg.max_particles = int(max_particles)
         cfg.stream = stream
         cfg.external_stream = 1 if external_stream else 0
+        cfg.slab_max_nx = int(slab_max_nx)
         self.grid = (cfg.grid_x, cfg.grid_y, cfg.grid_z)
         self.max_particles = int(max_particles)
         self.slab = slab
@@ -281,6 +282,11 @@ class Handle:
             self._h, counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), counts.shape[0],
             ctypes.c_void_p(dev_out), int(capacity_records)))
 
+    def set_slab(self, slab_x0, slab_nx):
+        """flowmpm_set_slab: re-cuts the handle (between steps; follow with find_leavers under the new cut)."""
+        self._chk(self.L.flowmpm_set_slab(self._h, int(slab_x0), int(slab_nx)))
+        self.slab = (int(slab_x0), int(slab_nx))
+
     # one slab step in six calls (include/flowmpm.h); buffers are device addresses, 0 / None = no neighbour
     def slab_step_begin(self):
         self._chk(self.L.flowmpm_slab_step_begin(self._h))
@@ -315,7 +321,7 @@ class SlabGroup:
     """flowmpm_slab_group: a decomposed domain behind one object, all slabs driven by this thread (on
     one device, or one slab per device over RCCL).  Mirrors Handle where the calls exist for a group."""
 
-    def __init__(self, grid, plane_starts, max_particles, devices=None, rebin_interval=64):
+    def __init__(self, grid, plane_starts, max_particles, devices=None, rebin_interval=64, slab_max_nx=0):
         self.L = _lib.load()
         self.grid = tuple(int(g) for g in grid)
         self.plane_starts = [int(x) for x in plane_starts]
@@ -324,6 +330,7 @@ class SlabGroup:
         cfg = _lib.Config()
         cfg.grid_x, cfg.grid_y, cfg.grid_z = self.grid
         cfg.algorithm, cfg.rebin_interval = _lib.ALGO_TILED, int(rebin_interval)
+        cfg.slab_max_nx = int(slab_max_nx)
         cfg.device = int(devices[0]) if devices else 0
         starts = (ctypes.c_int32 * (self.world + 1))(*self.plane_starts)
         devs = (ctypes.c_int32 * self.world)(*[int(d) for d in devices]) if devices else None
@@ -408,6 +415,19 @@ class SlabGroup:
         out = np.zeros((max(total, 1), _lib.FIELD_WIDTH[field]), dtype=np.float32)
         self._chk(self.L.flowmpm_slab_group_download_field(self._g, int(field), _fp(out), out.shape[0]))
         return out[:total]
+
+    def rebalance(self, max_move_fraction=0.1):
+        """flowmpm_slab_group_rebalance: re-cuts the slabs at the particle quantiles of the moment; True when
+        the cut moved (plane_starts and the handles' slabs are refreshed)."""
+        changed = ctypes.c_int32()
+        self._chk(self.L.flowmpm_slab_group_rebalance(self._g, float(max_move_fraction), ctypes.byref(changed)))
+        if changed.value:
+            starts = (ctypes.c_int32 * (self.world + 1))()
+            self._chk(self.L.flowmpm_slab_group_plane_starts(self._g, starts))
+            self.plane_starts = [int(x) for x in starts]
+            for r, h in enumerate(self.handles):
+                h.slab = (self.plane_starts[r], self.plane_starts[r + 1] - self.plane_starts[r])
+        return bool(changed.value)
 
     def conservation(self):
         out = np.zeros(5, dtype=np.int64)

@@ -77,6 +77,35 @@ def plane_starts_from_histogram(hist, world):
     return starts
 
 
+def limited_plane_starts(hist, current, max_nx, budget):
+    """The balanced cut, approached from the current one: boundary r moves toward its balanced place only as
+    far as at most `budget` particles change hands through it (one plane always may), and no slab becomes
+    wider than max_nx[r] or narrower than 2 planes.  The rule of the library's slab groups
+    (flow_amd/csrc/kernels_migrate.h), so that every host cuts alike."""
+    hist = np.asarray(hist, dtype=np.int64)
+    world = len(current) - 1
+    want = plane_starts_from_histogram(hist, world)
+    nxt = [int(c) for c in current]
+    for r in range(1, world):
+        cut = nxt[r]
+        step = 1 if want[r] > cut else -1
+        moved = 0
+        while cut != want[r]:
+            plane = cut if step > 0 else cut - 1
+            if moved > 0 and moved + int(hist[plane]) > budget:
+                break
+            moved += int(hist[plane])
+            cut += step
+        nxt[r] = cut
+    for r in range(1, world):
+        nxt[r] = max(nxt[r], nxt[r - 1] + 2)
+    for r in range(world - 1, 0, -1):
+        nxt[r] = min(nxt[r], nxt[r + 1] - 2)
+    if any(nxt[r + 1] - nxt[r] > max_nx[r] for r in range(world)):
+        return [int(c) for c in current]
+    return nxt
+
+
 class _Transport:
     """Point-to-point exchange over torch.distributed.  RCCL moves device tensors directly;
     gloo (CPU rehearsals) cannot send device tensors, so they are staged through the host."""
@@ -125,14 +154,15 @@ class GpuSlabBackend:
     stream (so RCCL operations issued through torch order against the kernels) plus torch
     tensors as send/receive staging."""
 
-    def __init__(self, grid, slab_x0, slab_nx, max_particles, device, algorithm, rebin_interval):
+    def __init__(self, grid, slab_x0, slab_nx, max_particles, device, algorithm, rebin_interval, slab_max_nx=0):
         from .simulator import Handle
         self.torch_device = torch.device("cuda", device)
         torch.cuda.set_device(self.torch_device)
         stream = torch.cuda.current_stream(self.torch_device).cuda_stream
         self.handle = Handle(grid, max_particles, device=device, algorithm=algorithm,
                              rebin_interval=rebin_interval, slab=(slab_x0, slab_nx), stream=stream,
-                             external_stream=True)
+                             external_stream=True, slab_max_nx=slab_max_nx)
+        self.slab_max_nx = max(slab_max_nx, slab_nx)
         self.plane_words = grid[1] * grid[2] * 4
         self.max_particles = max_particles
         self._leavers = torch.empty((max(max_particles // 4, 1024), RECORD_WORDS), dtype=torch.float32,
@@ -225,7 +255,8 @@ class GpuSlabBackend:
 
 class SlabSimulation:
     def __init__(self, grid, plane_starts, rank, world, max_particles=0, device=0,
-                 algorithm=_lib.ALGO_TILED, rebin_interval=1, dist=None, torch_device=None, backend=None):
+                 algorithm=_lib.ALGO_TILED, rebin_interval=1, dist=None, torch_device=None, backend=None,
+                 slab_max_nx=0):
         self.grid = tuple(int(g) for g in grid)
         self.plane_starts = [int(s) for s in plane_starts]
         assert len(self.plane_starts) == world + 1 and self.plane_starts[0] == 0
@@ -234,7 +265,8 @@ class SlabSimulation:
         self.x0 = self.plane_starts[rank]
         self.nx = self.plane_starts[rank + 1] - self.x0
         self.backend = backend if backend is not None else GpuSlabBackend(
-            self.grid, self.x0, self.nx, max_particles, device, algorithm, rebin_interval)
+            self.grid, self.x0, self.nx, max_particles, device, algorithm, rebin_interval, slab_max_nx)
+        self.recuts = 0
         self.transport = _Transport(dist) if (dist is not None and world > 1) else None
         # the tiled algorithm's two-pass p2g (mass, then summed momentum); other backends keep
         # the reference's p2g1 / p2g2
@@ -550,6 +582,34 @@ class SlabSimulation:
     def _complete(self, posted):
         if self.transport is not None:
             self.transport.complete(posted)
+
+    def rebalance(self, max_move_fraction=0.1):
+        """Re-cuts the slabs at the particle quantiles of the moment (a collective: every rank calls it,
+        every few steps): the per-plane histogram is summed over the ranks, every rank derives the same new
+        cut from it (limited_plane_starts), re-cuts its handle (flowmpm_set_slab; the handle must have been
+        created with slab_max_nx) and starts the migration of the planes that changed hands, which the
+        next step completes.  Returns True when the cut moved."""
+        if self.transport is None:
+            return False
+        self._finish_migration()
+        h = self.backend.handle
+        hist = torch.from_numpy(h.plane_histogram()).to(self._comm_device())
+        self.dist.all_reduce(hist)
+        hist = hist.cpu().numpy()
+        total = int(hist.sum())
+        limits = torch.tensor([self.backend.slab_max_nx], dtype=torch.int64, device=self._comm_device())
+        gathered = torch.empty(self.world, dtype=torch.int64, device=self._comm_device())
+        self.dist.all_gather_into_tensor(gathered, limits)
+        new = limited_plane_starts(hist, self.plane_starts, [int(v) for v in gathered.cpu()],
+                                   int(max_move_fraction * total / self.world))
+        if new == self.plane_starts:
+            return False
+        self.plane_starts = new
+        self.x0, self.nx = new[self.rank], new[self.rank + 1] - new[self.rank]
+        h.set_slab(self.x0, self.nx)
+        self.recuts += 1
+        self._begin_migration()
+        return True
 
     def resident(self):
         self._finish_migration()

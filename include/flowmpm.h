@@ -139,6 +139,9 @@ typedef struct {
     void   *stream;                   /* hipStream_t to enqueue on when external_stream != 0
                                          (NULL is then the device's default stream) */
     int32_t external_stream;          /* 0: the handle creates and owns its stream */
+    int32_t slab_max_nx;              /* slab handles: the most planes flowmpm_set_slab may give this
+                                         handle later (its grids are allocated for that many); 0 means
+                                         slab_nx, i.e. a slab that is never re-cut */
 } flowmpm_config;
 
 /* The uniforms the hot path reads (SIM:141-151, 256-260) plus the clock that
@@ -397,6 +400,16 @@ int flowmpm_pack_leavers(flowmpm_sim *sim, const int64_t *counts, int32_t n_rank
 /* Appends packed records that arrived from other ranks. */
 int flowmpm_insert_arrivals(flowmpm_sim *sim, const void *dev_in, int64_t count);
 
+/* Re-cuts a slab handle: from now on it owns planes [slab_x0, slab_x0 + slab_nx) (slab_nx at most the
+ * slab_max_nx it was created with).  Called between steps, on every slab of the decomposition with the
+ * new cut, and followed by flowmpm_find_leavers with the new plane_starts: the particles of the planes
+ * that changed hands are then leavers and travel through the ordinary migration of the next step
+ * (flowmpm_pack_leavers / flowmpm_insert_arrivals), so a re-cut costs one step's migration of those
+ * planes and a forced re-bin.  Both grids of the handle are cleared (every step rebuilds them).  What a
+ * host does every few steps from the summed flowmpm_plane_histogram when the fluid moves through the
+ * domain (the dam-break configuration); results do not depend on the cut. */
+int flowmpm_set_slab(flowmpm_sim *sim, int32_t slab_x0, int32_t slab_nx);
+
 /* ---- One step of a FLOWMPM_ALGO_TILED slab handle in six calls, in this order (any other order is
  * FLOWMPM_ERR_INVALID).  Each call only enqueues; the gaps between them are where the host's transport
  * acts.  This is the stage sequence above (clearGrid, mass pass of the stayers, ... g2p of the boundary
@@ -471,6 +484,16 @@ int flowmpm_slab_group_download_field(flowmpm_slab_group *group, int32_t field, 
 int flowmpm_slab_group_conservation(flowmpm_slab_group *group, int64_t sums[5]);
 /* Particles handed from slab to slab so far, and the farthest destination in slabs (1 = a neighbour). */
 int flowmpm_slab_group_migration_stats(flowmpm_slab_group *group, int64_t *migrated, int32_t *max_hop);
+/* Re-balances the group: sums flowmpm_plane_histogram over the slabs, cuts the domain at the particle
+ * quantiles again, and -- if the cut differs -- re-cuts every slab (flowmpm_set_slab; the group must have
+ * been created with base->slab_max_nx large enough) and starts the migration of the planes that changed
+ * hands, which the next step completes.  A boundary moves only as far as at most `max_move_fraction` of
+ * the mean particle count per slab changes hands through it in one call (0 < fraction <= 1; the leaver
+ * buffers hold a quarter of a slab's capacity), so a large imbalance is worked off over several calls.
+ * *changed (may be NULL) receives 1 when the cut moved.  Waits for the device (a few times per call):
+ * meant for every 10 to 100 steps. */
+int flowmpm_slab_group_rebalance(flowmpm_slab_group *group, double max_move_fraction, int32_t *changed);
+int flowmpm_slab_group_plane_starts(flowmpm_slab_group *group, int32_t *plane_starts /* n_slabs + 1 */);
 /* RCCL in a world of one on `device`: a communicator, `words` 32-bit words sent to itself inside one group
  * call, compared on the host.  What a host runs before it creates a group over several devices. */
 int flowmpm_rccl_selftest(int32_t device, int64_t words);

@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--mode-case", default=None, help="a case name of tests/mode_cases.py (grid 128,64,64)")
     ap.add_argument("--dt", type=float, default=DEFAULT_UNIFORMS["dt"],
                     help="a large dt makes particles jump over whole slabs in one step")
+    ap.add_argument("--recut-every", type=int, default=0,
+                    help="gpu backend: SlabSimulation.rebalance() after every k-th step (slabs change width)")
     ap.add_argument("--leaver-capacity-of-rank1", type=int, default=-1,
                     help="oracle backend: rank 1 claims a leaver buffer of this many records; the run must then "
                          "end with the capacity error on EVERY rank (marker files), not with a hang")
@@ -233,7 +235,7 @@ def main():
     else:
         algo = _lib.ALGO_TILED if args.algorithm == "tiled" else _lib.ALGO_SCATTER
         sim = SlabSimulation(grid, starts, rank, world, max_particles=n, device=0, algorithm=algo,
-                             rebin_interval=2, dist=dist)
+                             rebin_interval=2, dist=dist, slab_max_nx=grid[0] if args.recut_every else 0)
     sim.scatter_initial_particles(rec[lo:hi], np.arange(lo, hi, dtype=np.int32))
     if mode_fields is not None:
         sim.set_mode_uniforms(mode_cases.fill(_lib.ModeUniforms, mode_fields))
@@ -241,6 +243,8 @@ def main():
         for k in range(args.steps):
             sim.set_uniforms(**dict(DEFAULT_UNIFORMS, dt=args.dt, time=0.25 * k, **mode_uni))
             sim.step()
+            if args.recut_every and k % args.recut_every == args.recut_every - 1 and k < args.steps - 1:
+                sim.rebalance(0.2)
         sim.synchronize()
     except _lib.FlowMpmError as exc:
         if args.leaver_capacity_of_rank1 < 0 or exc.code != _lib.ERR_CAPACITY:
@@ -250,6 +254,7 @@ def main():
         return      # no collective may follow: every rank left the step at the same point
     totals = sim.conservation()
     out_rec, out_ids = sim.download()
+    starts, x0, nx = sim.plane_starts, sim.x0, sim.nx        # a re-cut may have moved them
     if args.backend == "oracle":
         cell, cellf = sim.backend.owned_grid()
     else:
@@ -257,7 +262,7 @@ def main():
         cell = sim.backend.handle.download_grid_i32()[per:(nx + 1) * per]
         cellf = sim.backend.handle.download_grid_f32()[per:(nx + 1) * per]
     np.savez(os.path.join(args.out, "rank%d.npz" % rank), rec=out_rec, ids=out_ids, cell=cell, cellf=cellf,
-             starts=np.asarray(starts), totals=totals, max_hop=sim.max_hop)
+             starts=np.asarray(starts), totals=totals, max_hop=sim.max_hop, recuts=getattr(sim, "recuts", 0))
     sim.close()
     dist.barrier()
     dist.destroy_process_group()

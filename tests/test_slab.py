@@ -481,3 +481,84 @@ def test_native_slab_group_generates_its_scene_and_refuses_bad_placements():
 def test_rccl_world_of_one_sends_to_itself():
     from flow_amd.simulator import rccl_selftest
     rccl_selftest(0, 1 << 18)
+
+
+def test_limited_plane_starts_rule():
+    from flow_amd.slab import limited_plane_starts, plane_starts_from_histogram
+    hist = np.zeros(64, dtype=np.int64)
+    hist[4:20] = 1000                       # everything sits at low x
+    even = [0, 16, 32, 48, 64]
+    want = plane_starts_from_histogram(hist, 4)
+    assert want == [0, 8, 12, 16, 64]
+    # an unlimited budget goes all the way, widths permitting
+    assert limited_plane_starts(hist, even, [64] * 4, 10 ** 9) == want
+    # a budget of 2.5 planes' particles moves every boundary by at most 2 occupied planes (empty ones are free)
+    step = limited_plane_starts(hist, even, [64] * 4, 2500)
+    moved = [int(hist[min(a, b):max(a, b)].sum()) for a, b in zip(step, even)]
+    assert max(moved) <= 2500 and step != even
+    # repeated calls converge on the balanced cut
+    cur = even
+    for _ in range(20):
+        cur = limited_plane_starts(hist, cur, [64] * 4, 2500)
+    assert cur == want
+    # a slab that may not grow leaves the cut alone
+    assert limited_plane_starts(hist, even, [16, 16, 16, 16], 10 ** 9) == even
+
+
+@pytest.mark.gpu
+def test_recutting_the_slabs_while_running_keeps_the_bits(oracle_binding):
+    """flowmpm_slab_group_rebalance every other step on particles that stream through the domain: slabs
+    change width (planes and their particles change hands through the ordinary migration), and grid and
+    particles still equal the single-domain oracle's bit for bit."""
+    from flow_amd import SlabGroup
+
+    grid, n, steps, dt = (96, 16, 16), 30000, 12, 1.0
+    rec = moving_particles(n, grid, seed=61, vel=2.0)
+    rec[:, 0] = 4.0 + (rec[:, 0] - rec[:, 0].min()) * 0.35          # a column at low x ...
+    rec[:, 4] = np.abs(rec[:, 4]) + 1.5                              # ... streaming toward high x
+    group = SlabGroup(grid, [0, 24, 48, 72, 96], n, rebin_interval=3, slab_max_nx=96)
+    group.upload_particles(rec)
+    cuts = [list(group.plane_starts)]
+    for k in range(steps):
+        group.set_uniforms(**dict(DEFAULT_UNIFORMS, dt=dt, time=0.25 * k))
+        group.step(1, 0.0)
+        # (not after the last step: a re-cut clears the grids, which the comparisons below read)
+        if k % 2 == 1 and k < steps - 1 and group.rebalance(0.5):
+            cuts.append(list(group.plane_starts))
+    assert len(cuts) >= 3, "the cut should have moved several times: %r" % cuts
+    _, per = group.num_particles()
+    assert per.max() / per.mean() < 1.6, per
+    want = rec.copy()
+    orc = oracle_binding.Oracle(grid, threads=8)
+    for k in range(steps):
+        orc.step(want, oracle_binding.make_uniforms(grid, n, **dict(DEFAULT_UNIFORMS, dt=dt, time=0.25 * k)))
+    assert_bits_equal(group.download_particles(), want, "particles after %d re-cuts" % (len(cuts) - 1))
+    totals = group.conservation()
+    assert np.array_equal(totals[:4], orc.cell.astype(np.int64).sum(axis=0)) and int(totals[4]) == n
+    plane = grid[1] * grid[2]
+    starts = group.plane_starts
+    for r, h in enumerate(group.handles):
+        x0, x1 = starts[r], starts[r + 1]
+        assert h.local_grid() == (x0 - 1, x1 - x0 + 2)
+        assert np.array_equal(h.download_grid_i32()[plane:(x1 - x0 + 1) * plane], orc.cell[x0 * plane:x1 * plane]), "slab %d grid" % r
+    # a group created without room to grow refuses politely: the cut stays
+    fixed = SlabGroup(grid, [0, 24, 48, 72, 96], n)
+    fixed.upload_particles(rec)
+    fixed.step(1, 0.0)
+    assert fixed.rebalance(0.5) is False and fixed.plane_starts == [0, 24, 48, 72, 96]
+    fixed.close()
+    group.close()
+
+
+@pytest.mark.gpu
+def test_three_rank_rehearsal_with_recuts(oracle_binding, tmp_path):
+    """Three processes on cuda:0 over gloo: SlabSimulation.rebalance() after every second step (histogram
+    all-reduce, flowmpm_set_slab, migration of the planes that changed hands) -- still the single domain's
+    bits, with slabs that ended up at another width than they started."""
+    grid, n, steps, vel = (120, 16, 16), 12000, 8, 3.0
+    _launch(3, tmp_path, "--backend", "gpu", "--grid", "%d,%d,%d" % grid, "--particles", str(n),
+            "--steps", str(steps), "--vel", str(vel), "--recut-every", "2")
+    rec, orc = _reference_run(oracle_binding, grid, n, steps, vel)
+    _check_against_single_domain(tmp_path, 3, rec, orc, grid)
+    d = np.load(os.path.join(tmp_path, "rank0.npz"))
+    assert int(d["recuts"]) >= 1 and list(d["starts"]) != equal_plane_starts(grid[0], 3), list(d["starts"])
