@@ -68,6 +68,11 @@ def parse_args():
                     help="gloo = rehearsal of the multi-rank path on fewer GPUs than ranks (host-staged transport)")
     ap.add_argument("--slab-yz", type=int, default=512, help="y and z extent of the multi-GPU domain")
     ap.add_argument("--slab-x-per-gpu", type=int, default=64)
+    ap.add_argument("--recut-every", type=int, default=-1,
+                    help="N>1: re-cut the slabs at the particle quantiles every k steps (SlabSimulation.rebalance); "
+                         "-1 = 10 for the dam-break scene, whose column collapses through the domain, else never")
+    ap.add_argument("--recut-fraction", type=float, default=0.2,
+                    help="at most this fraction of a slab's mean particle count changes hands through a cut per re-cut")
     ap.add_argument("--one-slab", action="store_true",
                     help="N=1 through the multi-GPU code path: one 64 x 512 x 512 slab, no neighbour (what one "
                          "rank of the weak-scaling runs computes, without the exchanges)")
@@ -459,13 +464,25 @@ def run_distributed(args):
     hist = _lib.scene_plane_histogram(kind, n_total, grid, seed=seed, fill=0.25, device=local_rank)
     starts = plane_starts_from_histogram(hist, world)
     share = int(hist[starts[rank]:starts[rank + 1]].sum())
+    recut = args.recut_every if args.recut_every >= 0 else (10 if args.scene == "dam_break" else 0)
+    if world == 1:
+        recut = 0
     sim = SlabSimulation(grid, starts, rank, world, max_particles=max(int(n_per * 2.5), share + share // 4),
                          device=local_rank, algorithm=algo, rebin_interval=args.rebin_interval, dist=dist,
-                         torch_device=torch.device("cuda", local_rank))
+                         torch_device=torch.device("cuda", local_rank), slab_max_nx=grid[0] if recut else 0)
     sim.generate_initial_particles(kind, n_total, seed=seed, fill=0.25)
     sim.set_uniforms(**uniforms)
-    for _ in range(args.warmup):
-        sim.step()
+    steps_done = 0
+
+    def advance(count):
+        nonlocal steps_done
+        for _ in range(count):
+            sim.step()
+            steps_done += 1
+            if recut and steps_done % recut == 0:
+                sim.rebalance(args.recut_fraction)
+
+    advance(args.warmup)
     sim.synchronize()
     handle = getattr(sim.backend, "handle", None)
     n_start = sim.resident()
@@ -476,8 +493,7 @@ def run_distributed(args):
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sim.step()
+    advance(args.steps)
     sim.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -519,7 +535,8 @@ def run_distributed(args):
                        "scene": args.scene, "particles": n_total, "grid": list(grid), "algorithm": args.algorithm,
                        "noise": args.noise, "timing_stride": args.timing_stride,
                        "rebin_interval": args.rebin_interval, "parallelism": "slab%d" % world,
-                       "plane_starts": [int(s) for s in starts], "resident_per_rank_end": per_rank,
+                       "plane_starts": [int(s) for s in starts], "plane_starts_end": [int(s) for s in sim.plane_starts],
+                       "recut_every": recut, "recuts": sim.recuts, "resident_per_rank_end": per_rank,
                        "kernel_ms_per_step_per_rank": per_rank_busy,
                        "rebins_per_rank": [int(b[1].item()) for b in busy_all],
                        "particles_sent_away_per_step_per_rank": [round(float(b[2].item()) / args.steps, 1) for b in busy_all],

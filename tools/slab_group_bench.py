@@ -38,6 +38,13 @@ def main():
     ap.add_argument("--windows", type=int, default=1, help="timed windows of --steps steps, back to back")
     ap.add_argument("--single", action="store_true", help="also time the same problem as one single-domain handle")
     ap.add_argument("--profile-slab", type=int, default=-1, help="HIP-event timing of this slab's launches")
+    ap.add_argument("--native", action="store_true",
+                    help="drive the slabs through flowmpm_slab_group (the library's own lock-step) instead of "
+                         "the Python lock-step over the six step calls")
+    ap.add_argument("--recut-every", type=int, default=0,
+                    help="--native: flowmpm_slab_group_rebalance after every k-th step (0: the cut stays)")
+    ap.add_argument("--recut-fraction", type=float, default=0.1)
+    ap.add_argument("--report-every", type=int, default=0, help="--native: resident particles per slab every k steps")
     args = ap.parse_args()
 
     world, n_per = args.world, 1 << args.particles_log2
@@ -52,6 +59,39 @@ def main():
     share = [int(hist[starts[r]:starts[r + 1]].sum()) for r in range(world)]
     out = {"grid": list(grid), "particles": n, "world": world, "plane_starts": starts, "particles_per_slab": share,
            "noise": args.noise, "scene": args.scene}
+    if args.native:
+        from flow_amd import SlabGroup
+        cap = int(max(share) * 2.5) + 4096
+        group = SlabGroup(grid, starts, cap, rebin_interval=64, slab_max_nx=grid[0] if args.recut_every else 0)
+        group.generate_particles(kind, n, seed=seed)
+        group.set_uniforms(**uni)
+        group.step(args.warmup, 0.0)
+        group.synchronize()
+        out["windows"], out["balance"] = [], []
+        done = 0
+        for _ in range(args.windows):
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                group.step(1, 0.0)
+                done += 1
+                if args.recut_every and done % args.recut_every == 0:
+                    group.rebalance(args.recut_fraction)
+                if args.report_every and done % args.report_every == 0:
+                    per = group.num_particles()[1]
+                    out["balance"].append({"step": done, "max_over_mean": round(float(per.max() / per.mean()), 4),
+                                           "plane_starts": list(group.plane_starts)})
+            group.synchronize()
+            ms = (time.perf_counter() - t0) / args.steps * 1e3
+            out["windows"].append({"ms_per_group_step": round(ms, 4), "ms_per_slab_step": round(ms / world, 4)})
+        per = group.num_particles()[1]
+        out["residents"] = [int(v) for v in per]
+        out["resident_max_over_mean"] = round(float(per.max() / per.mean()), 4)
+        out["plane_starts_end"] = list(group.plane_starts)
+        out["migrated"], out["max_hop"] = group.migration_stats()
+        out["rebins_per_slab"] = [h.timings()["rebin"]["performed"] for h in group.handles]
+        group.close()
+        print(json.dumps(out))
+        return
     group = LocalSlabGroup(grid, starts, [int(c * 1.3) + 4096 for c in share])
     for h in group.handles:
         h.generate_particles(kind, n, seed=seed)
