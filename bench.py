@@ -29,6 +29,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec; measured copy ceiling is ~62
 BYTES = {
     "clearGrid": (0, 32), "p2g1": (60, 16), "p2g2": (56, 16), "updateGrid": (0, 32), "g2p": (96, 16),
 }
+# flowmpm_step has no clearGrid launch: its updateGrid also zeroes the fixed-point buffers of the step before
+# (the grid is double-buffered), so the `updateGrid` launch carries both stages' 64 bytes per cell.
 
 
 def parse_args():
@@ -331,7 +333,8 @@ def run_single(args):
     # windows hold the flow's re-bins and the spread-out fluid.  The timed window's figure stays on the
     # line as roofline.first_window.
     roof = first_roof
-    if steady is not None and all(steady_kernels[k]["launches"] for k in steady_kernels):
+    # (clearGrid has no launch of its own in flowmpm_step: updateGrid zeroes the older fixed-point set)
+    if steady is not None and all(steady_kernels[k]["launches"] for k in ("p2g1", "p2g2", "g2p")):
         roof, steady_per_kernel = roofline_of(steady_kernels, n, cells)
         roof["window"] = "steady: %d steps after the timed window, every %d-th step sampled" % (steady_steps, args.timing_stride)
         roof["first_window"] = {k: first_roof[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}

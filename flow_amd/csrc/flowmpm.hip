@@ -94,7 +94,15 @@ struct flowmpm_sim {
     // 2: the step's mass pass also counts the tiles; 1: a counting launch of its own; 0: off, the
     // standalone two-launch re-bin (FLOWMPM_RIDE_REBINS sets it, for A/B runs).
     int ride_rebins = 0;
+    // The fixed-point grid is double-buffered as two sets {momentum records, mass words}: {cell, mass_i} is
+    // the set the current step accumulates into, {cell_spare, mass_spare} the other one.
     int4 *cell = nullptr;        // momentum words (word 3 unused on the device)
+    int4 *cell_spare = nullptr;
+    int4 *cell_first = nullptr;  // the momentum buffer that owns bit 0 (the other one owns bit 3)
+    // {cell_spare, mass_spare} hold nothing but zeros and their tile bits are clear: the updateGrid of
+    // flowmpm_step zeroes the set of the step before while it visits its tiles, so the next step needs
+    // no clearGrid launch
+    bool spare_clean = false;
     int *mass_i = nullptr;       // mass words, one per cell
     // The float grid is non-zero only where this buffer is positive: the mass words of the step
     // whose updateGrid last wrote it.  Either mass_i or mass_spare.
@@ -113,9 +121,10 @@ struct flowmpm_sim {
     bool stayers_done = false;
     int slab_phase = 0;          // which flowmpm_slab_step_* call comes next (0: _begin)
     int mass_bit(const int *buffer) const { return buffer == mass_first ? 2 : 4; }
+    int cell_bit(const int4 *buffer) const { return buffer == cell_first ? 1 : 8; }
     mpm::FixedGrid fixed() const
     {
-        return mpm::FixedGrid{reinterpret_cast<int *>(cell), mass_i, dirty, 1 | mass_bit(mass_i)};
+        return mpm::FixedGrid{reinterpret_cast<int *>(cell), mass_i, dirty, cell_bit(cell) | mass_bit(mass_i)};
     }
     // Work items whose arena reaches the planes a halo exchange changes (local planes 0, 1,
     // slab_nx, slab_nx + 1).  The arena of tile column tx spans local planes
@@ -263,20 +272,32 @@ int launch_check(flowmpm_sim *s, const char *what)
 // must survive until updateGrid has used them, so the step accumulates into the other buffer.
 int stage_clear_grid(flowmpm_sim *s, bool float_grid = true)
 {
+    unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
+    if (!float_grid && s->mass_i == s->mass_of_cellf) {
+        // the set that describes the float grid must survive until updateGrid: accumulate into the other one
+        std::swap(s->mass_i, s->mass_spare);
+        std::swap(s->cell, s->cell_spare);
+        const bool clean = s->spare_clean;
+        s->spare_clean = false;              // what is now the spare set is the dirty one
+        if (clean) {                         // the last updateGrid has cleared it already: no launch
+            s->tiles_marked = false;
+            return FLOWMPM_OK;
+        }
+    }
     TimedLaunch t;
     int rc = timing_events(s, FLOWMPM_KERNEL_CLEAR_GRID, &t);
     if (rc) return rc;
-    unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
     if (float_grid) {
         hipExtLaunchKernelGGL(mpm::clear_grid_kernel<true>, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
                               s->cell, s->mass_i, s->cellf, s->mass_spare, s->local_cells);
+        HIP_TRY(s, hipMemsetAsync(s->cell_spare, 0, (size_t)s->local_cells * sizeof(int4), s->stream));
         s->mass_of_cellf = s->mass_i;       // all zero, like the float grid
+        s->spare_clean = true;
         if (s->dirty) HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
     } else {
-        if (s->mass_i == s->mass_of_cellf) std::swap(s->mass_i, s->mass_spare);
         if (s->dirty)
             hipExtLaunchKernelGGL(mpm::clear_tiles_kernel, dim3(s->tiled.n_tiles), dim3(256), 0, s->stream, t.start,
-                                  t.stop, 0, s->cell, s->mass_i, s->dirty, s->mass_bit(s->mass_i),
+                                  t.stop, 0, s->cell, s->mass_i, s->dirty, s->cell_bit(s->cell), s->mass_bit(s->mass_i),
                                   mpm::tile_dims(s->tiled), s->params, s->tile_range());
         else
             hipExtLaunchKernelGGL(mpm::clear_grid_kernel<false>, dim3(blocks), dim3(256), 0, s->stream, t.start,
@@ -294,7 +315,7 @@ inline bool is_tiled(const flowmpm_sim *s);
 int assume_all_tiles_dirty_unless_marked(flowmpm_sim *s)
 {
     if (!s->dirty || s->tiles_marked) return FLOWMPM_OK;
-    HIP_TRY(s, hipMemsetAsync(s->dirty, 0x07, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
+    HIP_TRY(s, hipMemsetAsync(s->dirty, 0x0F, (size_t)s->tiled.n_tiles * sizeof(int), s->stream));
     s->tiles_marked = true;
     return FLOWMPM_OK;
 }
@@ -396,7 +417,9 @@ int stage_p2g_mass_arrivals(flowmpm_sim *s)
     return FLOWMPM_OK;
 }
 
-int stage_update_grid(flowmpm_sim *s, bool boundary_only = false)
+// clear_old: the caller is a whole step (flowmpm_step, the slab step), which no host call can interleave:
+// the fixed-point set of the step before is zeroed on the way, and the next step starts without a clearGrid.
+int stage_update_grid(flowmpm_sim *s, bool boundary_only = false, bool clear_old = false)
 {
     if (boundary_only && !(s->slab && s->dirty))
         return fail(s, FLOWMPM_ERR_INVALID, "UPDATE_GRID_BOUNDARY is for tiled slab handles");
@@ -411,11 +434,15 @@ int stage_update_grid(flowmpm_sim *s, bool boundary_only = false)
         const int columns = std::min(s->tiled.tiles_x, (r.always_lo + 1) + std::max(0, s->tiled.tiles_x - std::max(r.always_hi, r.always_lo + 1)));
         tile_blocks = (unsigned)(columns * s->tiled.tiles_y * s->tiled.tiles_z);
     }
+    // the older set can be zeroed here when it is not the one being updated from
+    const bool zero_old = clear_old && !boundary_only && s->dirty && s->mass_of_cellf != s->mass_i &&
+                          s->mass_of_cellf == s->mass_spare;
     if (s->dirty)
         hipExtLaunchKernelGGL(mpm::update_grid_tiles_kernel, dim3(tile_blocks), dim3(256), 0, s->stream, t.start,
                               t.stop, 0, s->cell, s->mass_i, s->mass_of_cellf, s->cellf, s->dirty,
                               boundary_only ? -1 : (s->mass_bit(s->mass_i) | s->mass_bit(s->mass_of_cellf)),
-                              mpm::tile_dims(s->tiled), s->params, s->tile_range());
+                              mpm::tile_dims(s->tiled), s->params, s->tile_range(), s->cell_spare,
+                              zero_old ? (s->cell_bit(s->cell_spare) | s->mass_bit(s->mass_spare)) : 0);
     else
         hipExtLaunchKernelGGL(mpm::update_grid_kernel, dim3(blocks), dim3(256), 0, s->stream, t.start, t.stop, 0,
                               s->cell, s->mass_i, s->mass_of_cellf, s->cellf, s->local_cells, s->params);
@@ -423,6 +450,7 @@ int stage_update_grid(flowmpm_sim *s, bool boundary_only = false)
         s->mass_spare = s->mass_of_cellf;
         s->mass_of_cellf = s->mass_i;
     }
+    if (zero_old) s->spare_clean = true;
     return launch_check(s, "update_grid");
 }
 
@@ -721,6 +749,10 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->cellf), cells_cap * sizeof(float4)));
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->mass_i), cells_cap * sizeof(int)));
         HIP_TRY(s, hipMemsetAsync(s->cell, 0, cells_cap * sizeof(int4), s->stream));
+        HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->cell_spare), cells_cap * sizeof(int4)));
+        HIP_TRY(s, hipMemsetAsync(s->cell_spare, 0, cells_cap * sizeof(int4), s->stream));
+        s->cell_first = s->cell;
+        s->spare_clean = true;
         HIP_TRY(s, hipMemsetAsync(s->mass_i, 0, cells_cap * sizeof(int), s->stream));
         HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->mass_spare), cells_cap * sizeof(int)));
         HIP_TRY(s, hipMemsetAsync(s->mass_spare, 0, cells_cap * sizeof(int), s->stream));
@@ -786,6 +818,7 @@ int flowmpm_destroy(flowmpm_sim *s)
     if (s->store.base[0]) (void)hipFree(s->store.base[0]);
     if (s->store.base[1]) (void)hipFree(s->store.base[1]);
     if (s->cell) (void)hipFree(s->cell);
+    if (s->cell_spare) (void)hipFree(s->cell_spare);
     if (s->mass_i) (void)hipFree(s->mass_i);
     if (s->mass_spare) (void)hipFree(s->mass_spare);
     if (s->dirty) (void)hipFree(s->dirty);
@@ -1092,7 +1125,7 @@ int flowmpm_step(flowmpm_sim *s, int32_t n_steps, double dtime)
             if ((rc = stage_p2g1(s))) break;
             if ((rc = stage_p2g2(s))) break;
         }
-        if ((rc = stage_update_grid(s))) break;
+        if ((rc = stage_update_grid(s, false, true))) break;
         if ((rc = stage_g2p(s))) break;
         // bound the number of live event pairs
         if (s->profiling && s->events_used > 4096 && (rc = timing_collect(s))) break;
@@ -1484,6 +1517,8 @@ int flowmpm_set_slab(flowmpm_sim *s, int32_t slab_x0, int32_t slab_nx)
     s->local_cells = (long long)s->params.local_nx * s->cfg.grid_y * s->cfg.grid_z;
     // the planes the local grids hold have changed: what they held means nothing any more
     HIP_TRY(s, hipMemsetAsync(s->cell, 0, (size_t)s->local_cells * sizeof(int4), s->stream));
+    HIP_TRY(s, hipMemsetAsync(s->cell_spare, 0, (size_t)s->local_cells * sizeof(int4), s->stream));
+    s->spare_clean = true;
     HIP_TRY(s, hipMemsetAsync(s->cellf, 0, (size_t)s->local_cells * sizeof(float4), s->stream));
     HIP_TRY(s, hipMemsetAsync(s->mass_i, 0, (size_t)s->local_cells * sizeof(int), s->stream));
     HIP_TRY(s, hipMemsetAsync(s->mass_spare, 0, (size_t)s->local_cells * sizeof(int), s->stream));
@@ -1600,7 +1635,7 @@ int flowmpm_slab_step_grid(flowmpm_sim *s)
     int rc = slab_step_enter(s, 4, "flowmpm_slab_step_grid");
     if (rc) return rc;
     s->slab_phase = 0;
-    if ((rc = stage_update_grid(s))) return rc;
+    if ((rc = stage_update_grid(s, false, true))) return rc;
     if ((rc = stage_g2p(s, 1))) return rc;
     s->slab_phase = 5;
     return FLOWMPM_OK;

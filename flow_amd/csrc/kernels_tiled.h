@@ -228,6 +228,10 @@ struct TiledWork {
     // Mass pass only: decide != 0 makes it the launch that decides whether a re-bin rides on the step
     // (rebin_due with these two) and latches the answer in RebinCtl::riding.
     int decide, interval, divisor;
+    // Mass pass only: scan_here != 0 makes the last workgroup of the pass's follow-up kernel build the next
+    // item set of a riding re-bin (scan_tiles with these two) -- a grid of few tiles needs no launch of its own
+    // for that.
+    int scan_here, chunk, sparse;
 };
 
 __device__ __forceinline__ int tile_of(float px, float py, float pz, const Params &P, TileDims td)
@@ -1388,6 +1392,15 @@ straggler_p2g_team_kernel(TiledWork w, FixedGrid g, Params P)
             atomicAdd(g.cell + 4 * cell + 2, ez);
         }
     }
+    if (!MOMENTUM && w.scan_here) {                      // uniform over the launch
+        // every particle of the step has been counted once the last workgroup arrives here
+        if (last_workgroup(&w.ctl->ticket) && w.ctl->riding == 2) {
+            const int next_set = w.ctl->item_set ^ 1;
+            scan_tiles(w.tile_count, w.n_tiles, const_cast<int *>(w.tile_start) + (long long)next_set * (w.n_tiles + 1),
+                       const_cast<int4 *>(w.items) + (long long)next_set * w.item_cap,
+                       const_cast<int *>(w.n_items) + next_set, w.item_cap, w.chunk, w.n, w.sparse, &w.ctl->dense_next);
+        }
+    }
 }
 
 template <bool MODES>
@@ -1497,17 +1510,17 @@ __device__ __forceinline__ long long tile_cell(int tile, int k, TileDims td, con
     return ((long long)*lx * P.gy + *y) * P.gz + *z;
 }
 
-// clearGrid of the fixed-point grid (SIM:262-277 without the float grid): the momentum records
-// of tiles with bit 0 set, the words of mass buffer `mass` of tiles with `mass_bit` set; both
+// clearGrid of the fixed-point grid (SIM:262-277 without the float grid): the momentum records `cell`
+// of tiles with `cell_bit` set, the words of mass buffer `mass` of tiles with `mass_bit` set; both
 // bits are cleared.
 __global__ void __launch_bounds__(256)
-clear_tiles_kernel(int4 *__restrict__ cell, int *__restrict__ mass, int *__restrict__ dirty, int mass_bit,
+clear_tiles_kernel(int4 *__restrict__ cell, int *__restrict__ mass, int *__restrict__ dirty, int cell_bit, int mass_bit,
                    TileDims td, Params P, TileRange r)
 {
     const int t = blockIdx.x;
     const bool always = tile_always(t, td, r);
     const int bits = dirty[t];
-    const bool do_cell = always || (bits & 1), do_mass = always || (bits & mass_bit);
+    const bool do_cell = always || (bits & cell_bit), do_mass = always || (bits & mass_bit);
     if (!do_cell && !do_mass) return;
     for (int k = threadIdx.x; k < kTX * kTY * kTZ; k += 256) {
         int lx, y, z;
@@ -1517,15 +1530,22 @@ clear_tiles_kernel(int4 *__restrict__ cell, int *__restrict__ mass, int *__restr
         if (do_mass) mass[c] = 0;
     }
     __syncthreads();                       // every thread has read the bits
-    if (threadIdx.x == 0) dirty[t] = bits & ~(1 | mass_bit);
+    if (threadIdx.x == 0) dirty[t] = bits & ~(cell_bit | mass_bit);
 }
 
 // updateGrid (SIM:395-429, see update_grid_kernel) over the tiles where this step's mass buffer
 // or the one that describes the float grid may be non-zero (`bits`).
+//
+// The fixed-point grid is double-buffered: a step accumulates into one set {cell, mass_i} while the set
+// of the step before, {cell_old, mass_of_cellf}, still tells this kernel which float cells the fluid has
+// left.  Once this kernel has read it that older set is dead, so -- clear_old_bits != 0 -- it is zeroed
+// here, in the tiles whose bits say it may hold something (the same tiles this launch visits anyway), and
+// the NEXT step accumulates into it without a clearGrid launch of its own.
 __global__ void __launch_bounds__(256)
 update_grid_tiles_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass_i,
-                         const int *__restrict__ mass_of_cellf, float4 *__restrict__ cellf,
-                         const int *__restrict__ dirty, int bits, TileDims td, Params P, TileRange r)
+                         int *__restrict__ mass_of_cellf, float4 *__restrict__ cellf,
+                         int *__restrict__ dirty, int bits, TileDims td, Params P, TileRange r,
+                         int4 *__restrict__ cell_old, int clear_old_bits)
 {
     // bits < 0: the always-visited (boundary) tiles only, and the launch holds just their columns -- block b
     // is tile (tx, b mod (tiles_y tiles_z)) with tx running over 0 .. always_lo, then the columns from always_hi on
@@ -1536,12 +1556,23 @@ update_grid_tiles_kernel(const int4 *__restrict__ cell, const int *__restrict__ 
         const int tx = column <= r.always_lo ? column : hi_first + (column - r.always_lo - 1);
         t = tx * per_column + (t - column * per_column);
     }
-    if (!(tile_always(t, td, r) || (bits >= 0 && (dirty[t] & bits)))) return;
+    const bool always = tile_always(t, td, r);
+    const int tile_bits = dirty[t];
+    const bool zero_old = clear_old_bits != 0 && (always || (tile_bits & clear_old_bits));
+    if (!(always || zero_old || (bits >= 0 && (tile_bits & bits)))) return;
     for (int k = threadIdx.x; k < kTX * kTY * kTZ; k += 256) {
         int lx, y, z;
         const long long i = tile_cell(t, k, td, P, &lx, &y, &z);
         if (i < 0) continue;
         update_grid_cell(cell, mass_i, mass_of_cellf, cellf, i, lx + P.x_off, y, z, P);
+        if (zero_old) {
+            cell_old[i] = make_int4(0, 0, 0, 0);
+            mass_of_cellf[i] = 0;
+        }
+    }
+    if (zero_old) {
+        __syncthreads();                   // every thread has read the bits
+        if (threadIdx.x == 0) dirty[t] = tile_bits & ~clear_old_bits;
     }
 }
 
@@ -1682,7 +1713,7 @@ inline TiledWork tiled_work(TiledState &T, StoreSel ss, long long n, StagePart s
                         T.straggler_list};
     if (sp.part != 1) T.stage_parity ^= 1;
     return TiledWork{ss, T.items, T.n_items, T.item_cap, T.key, T.rank, T.tile_count, T.tile_start, T.n_tiles, T.ctl, (int)n,
-                     tile_dims(T), sg, -2147483647 - 1, 2147483647, sp.part, sp.bnd_lo, sp.bnd_hi, 0, 0, 0};
+                     tile_dims(T), sg, -2147483647 - 1, 2147483647, sp.part, sp.bnd_lo, sp.bnd_hi, 0, 0, 0, 0, 0, 0};
 }
 
 // Upper bound of the work items any binning of n particles can produce.
@@ -1694,14 +1725,19 @@ inline unsigned item_bound(const TiledState &T, long long n)
 
 // Every tiled stage is: the tiled kernel, then the straggler kernel for what it left.
 // ev_start / ev_stop (may be null) receive the start and end timestamps of the tiled kernel.
-constexpr int kStragglerBlocks = 1024;
+// Workgroups of a follow-up kernel: a small scene's handful of stragglers does not need a thousand.
+constexpr int kStragglerBlocksMax = 1024;
+inline unsigned straggler_blocks(long long n)
+{
+    return (unsigned)std::min<long long>(kStragglerBlocksMax, std::max<long long>(32, n / 4096));
+}
 
 #define FLOWMPM_TILED_STAGE(kernel, straggler_kernel, grid_ptr)                                              \
     do {                                                                                                    \
         const TiledWork w = tiled_work(T, st, n);                                                           \
         hipExtLaunchKernelGGL(kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, ev_start,     \
                               ev_stop, 0, w, grid_ptr, P);                                                  \
-        hipLaunchKernelGGL(straggler_kernel, dim3(kStragglerBlocks), dim3(256), 0, stream, w, grid_ptr, P); \
+        hipLaunchKernelGGL(straggler_kernel, dim3(straggler_blocks(n)), dim3(256), 0, stream, w, grid_ptr, P); \
         return 0;                                                                                           \
     } while (0)
 
@@ -1732,7 +1768,10 @@ inline void launch_ride_scan(TiledState &T, long long n, hipStream_t stream)
 }
 
 // defer_scan: the caller launches the scan itself (launch_ride_scan), after it has counted the particles
-// this pass does not see (a slab's arrivals).
+// this pass does not see (a slab's arrivals).  Otherwise a grid of at most kScanInFollowUpTiles tiles is
+// scanned by the last workgroup of the pass's follow-up kernel (256 threads: fine for a few thousand tiles,
+// too slow for the 32,768 of a 256^3 grid, which keep the 1,024-thread launch).
+constexpr int kScanInFollowUpTiles = 4096;
 inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedGrid g, const Params &P, hipStream_t stream,
                                  hipEvent_t ev_start, hipEvent_t ev_stop, int keep_lo = -2147483647 - 1,
                                  int keep_hi = 2147483647, bool defer_scan = false)
@@ -1745,10 +1784,18 @@ inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedG
         w.decide = 1;
         w.interval = T.ride_interval;
         w.divisor = T.ride_divisor;
+        if (!defer_scan && T.n_tiles <= kScanInFollowUpTiles) {
+            w.scan_here = 1;
+            w.chunk = T.chunk;
+            w.sparse = T.sparse;
+            T.scan_after_mass = false;           // no launch of its own
+        }
     }
     hipExtLaunchKernelGGL(p2g_mass_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream, ev_start,
                           ev_stop, 0, w, g, P);
-    hipLaunchKernelGGL(straggler_p2g_team_kernel<false>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
+    // (with the scan inside it, the follow-up kernel is what the re-bin's timing events bracket)
+    hipExtLaunchKernelGGL(straggler_p2g_team_kernel<false>, dim3(straggler_blocks(n)), dim3(256), 0, stream,
+                          w.scan_here ? T.scan_ev_start : nullptr, w.scan_here ? T.scan_ev_stop : nullptr, 0, w, g, P);
     if (!defer_scan) launch_ride_scan(T, n, stream);
     return 0;
 }
@@ -1785,7 +1832,7 @@ inline int launch_p2g_momentum_tiled(TiledState &T, StoreSel st, long long n, Fi
     hipExtLaunchKernelGGL(p2g_momentum_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream,
                           ev_start, ev_stop, 0, w, g, P);
     if (sp.part != 1)
-        hipLaunchKernelGGL(straggler_p2g_team_kernel<true>, dim3(kStragglerBlocks), dim3(256), 0, stream, w, g, P);
+        hipLaunchKernelGGL(straggler_p2g_team_kernel<true>, dim3(straggler_blocks(n)), dim3(256), 0, stream, w, g, P);
     return 0;
 }
 
@@ -1812,7 +1859,7 @@ inline int launch_g2p_tiled(TiledState &T, StoreSel st, long long n, const float
         hipExtLaunchKernelGGL((g2p_tiled_kernel<MODES_, LISTED_>), grid, block, 0, stream, ev_start, ev_stop, 0,  \
                               w, cellf, P, modes);                                                                \
         if (sp.part != 1)                                                                                         \
-            hipLaunchKernelGGL(straggler_g2p_kernel<MODES_>, dim3(kStragglerBlocks), dim3(256), 0, stream, w,     \
+            hipLaunchKernelGGL(straggler_g2p_kernel<MODES_>, dim3(straggler_blocks(n)), dim3(256), 0, stream, w,  \
                                cellf, P, modes);                                                                  \
     } while (0)
     if (modes) {

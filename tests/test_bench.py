@@ -142,7 +142,8 @@ def test_the_single_gpu_line():
     assert set(roof["first_window"]) == {"kernel", "achieved", "frac", "avg_launch_ms"}
     assert abs(roof["avg_launch_ms"] - sum(steady["kernel_avg_ms"][k] for k in
                                            (("p2g1", "p2g2") if roof["kernel"] == "p2g" else (roof["kernel"],)))) < 2e-4
-    assert "frac" not in d["kernels"]["clearGrid"] and "frac" in d["kernels"]["g2p"]
+    assert "frac" not in d["kernels"]["updateGrid"] and "frac" in d["kernels"]["g2p"]
+    assert "clearGrid" not in d["kernels"]        # no launch of its own: updateGrid zeroes the older grid set
     assert roof["traffic"] is None and roof["traffic_source"] is None       # this workload was never profiled
 
 
