@@ -120,6 +120,9 @@ struct flowmpm_sim {
     long long arrivals_first = -1;
     bool stayers_done = false;
     int slab_phase = 0;          // which flowmpm_slab_step_* call comes next (0: _begin)
+    // a standalone re-bin may have moved the particles since the leavers were classified (a riding one
+    // completes inside its step, before the classification): flowmpm_pack_leavers then lets the device check
+    bool moved_since_find = false;
     int mass_bit(const int *buffer) const { return buffer == mass_first ? 2 : 4; }
     int cell_bit(const int4 *buffer) const { return buffer == cell_first ? 1 : 8; }
     mpm::FixedGrid fixed() const
@@ -534,6 +537,7 @@ int stage_rebin_if_needed(flowmpm_sim *s, bool ride)
     if (rc) return rc;
     std::string msg;
     const int form = ride ? s->ride_rebins : 0;
+    if (form == 0 || !T.valid) s->moved_since_find = true;       // the two-launch re-bin, if the device finds it due
     if (mpm::rebin_if_due(T, s->store, s->live, s->params, s->cfg.rebin_interval,
                           form ? s->drift_divisor : s->drift_divisor_standalone, s->stream, t.start, t.stop, &msg, form))
         return fail(s, FLOWMPM_ERR_HIP, "rebin: " + msg);
@@ -1694,6 +1698,7 @@ int flowmpm_find_leavers(flowmpm_sim *s, const int32_t *plane_starts, int32_t n_
     if (mpm::find_leavers(s->migration, s->store, s->resident, s->cfg.slab_x0, s->cfg.slab_nx, plane_starts, n_ranks,
                           reinterpret_cast<long long *>(dev_counts), epoch, repeat, s->stream, &msg))
         return fail(s, FLOWMPM_ERR_HIP, "find_leavers: " + msg);
+    if (!repeat) s->moved_since_find = false;
     return FLOWMPM_OK;
 }
 
@@ -1708,7 +1713,7 @@ int flowmpm_pack_leavers(flowmpm_sim *s, const int64_t *counts, int32_t n_ranks,
     std::string msg;
     // A re-bin between the classification and this call has moved the particles: the device repeats the
     // classification on the slots they occupy now, if and only if that happened (the store's binning epoch).
-    if (s->tiled.ctl && s->migration.classified == s->resident && s->migration.table.n == n_ranks) {
+    if (s->tiled.ctl && s->moved_since_find && s->migration.classified == s->resident && s->migration.table.n == n_ranks) {
         const mpm::RankTable table = s->migration.table;        // find_leavers rewrites the scratch's copy
         if (mpm::find_leavers(s->migration, s->store, s->resident, s->cfg.slab_x0, s->cfg.slab_nx, table.starts, n_ranks,
                               nullptr, &s->tiled.ctl->epoch, true, s->stream, &msg))
