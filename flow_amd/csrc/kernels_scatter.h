@@ -212,6 +212,24 @@ __device__ __forceinline__ void update_grid_cell(const int4 *__restrict__ cell, 
     cellf[i] = make_float4(vx, vy, vz, mass);
 }
 
+// The same with the three words of the cell already loaded (c is unused when the cell holds no mass).
+__device__ __forceinline__ void update_grid_cell_loaded(int4 c, int mass_word, int before, float4 *__restrict__ cellf,
+                                                        long long i, int x, int y, int z, const Params &P)
+{
+    float mass = decode_fixed(mass_word);
+    if (!(mass > 0.0f)) {
+        if (before > 0) cellf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    float vx = decode_fixed(c.x) / mass;
+    float vy = decode_fixed(c.y) / mass;
+    float vz = decode_fixed(c.z) / mass;
+    if (x < 2 || x > P.gx - 2) vx = 0.0f;
+    if (y < 2 || y > P.gy - 2) vy = 0.0f;
+    if (z < 2 || z > P.gz - 2) vz = 0.0f;
+    cellf[i] = make_float4(vx, vy, vz, mass);
+}
+
 __global__ void __launch_bounds__(256)
 update_grid_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass_i,
                    const int *__restrict__ mass_of_cellf, float4 *__restrict__ cellf, long long cells, Params P)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of library variants under build_variants/: parity tests with the variant loaded, then bench lines.
+# A/B of library variants under build_variants/ on one box: the parity and slab tests with each variant loaded
+# ("base" is taken as known good), then bench lines of every variant, interleaved.
 #   tools/variant_ab.sh name1 name2 ...
 set -o pipefail
 mkdir -p gpurun_out
@@ -13,3 +14,4 @@ for round in 1 2; do
 done
 tools/ab.sh "--steps 100 --warmup 20 --noise 1.0" "$@" || exit 1
 tools/ab.sh "--particles-log2 20 --grid 128,128,128 --steps 200 --warmup 40" "$@" || exit 1
+tools/ab.sh "--particles 81920 --grid 128,64,64 --steps 400 --warmup 100" "$@" || exit 1
