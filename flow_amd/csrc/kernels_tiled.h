@@ -917,6 +917,13 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     __shared__ int nb_count[27], nb_base[27];
     straggler_buf_init(sb);
     const Arena A = arena_of_tile(item.x, w.td, P);
+    // The first positions are requested before the arena is zeroed, and every later trip requests the next
+    // ones before it issues its atomics: a work item of this pass is a chain of memory round trips (the
+    // compute units hold all the workgroups they can, eight each), and each of them taken off the chain
+    // shortens the pass.
+    int j = item.y + threadIdx.x;
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    if (j < item.z) { px = st.slot(kPosX)[j]; py = st.slot(kPosY)[j]; pz = st.slot(kPosZ)[j]; }
     for (int i = threadIdx.x; i < kArenaCells; i += kTiledThreads) lds[i] = 0;
     const int tz0 = item.x % w.td.tiles_z, ty0 = (item.x / w.td.tiles_z) % w.td.tiles_y,
               tx0 = item.x / (w.td.tiles_z * w.td.tiles_y);
@@ -925,8 +932,10 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     // The tiles this work item adds to, for clearGrid and updateGrid (FixedGrid::dirty).  The
     // momentum pass scatters the same particles over the same cells and marks nothing.
     unsigned touched = 0;
-    for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
-        Stencil s = make_stencil(st.slot(kPosX)[j], st.slot(kPosY)[j], st.slot(kPosZ)[j]);
+    for (int jn; j < item.z; j = jn) {
+        Stencil s = make_stencil(px, py, pz);
+        jn = j + kTiledThreads;
+        if (jn < item.z) { px = st.slot(kPosX)[jn]; py = st.slot(kPosY)[jn]; pz = st.slot(kPosZ)[jn]; }
         // a slab's leavers (floor(x) outside the planes it owns) are about to be packed away: they are neither
         // scattered nor counted
         const bool leaver = s.cx + 1 < w.keep_lo || s.cx + 1 >= w.keep_hi;       // s.cx = floor(x) - 1
