@@ -232,6 +232,9 @@ struct TiledWork {
     // item set of a riding re-bin (scan_tiles with these two) -- a grid of few tiles needs no launch of its own
     // for that.
     int scan_here, chunk, sparse;
+    // Momentum pass with the mass pass's list at hand (p2g_momentum_tiled_kernel<true>): the workgroups from
+    // this block index on are the pass's follow-up work (straggler_p2g_team) inside the same launch.
+    int follow_from;
 };
 
 __device__ __forceinline__ int tile_of(float px, float py, float pz, const Params &P, TileDims td)
@@ -1051,11 +1054,24 @@ __device__ __forceinline__ void p2g_momentum_particle(const Stencil &s, float vx
         }
 }
 
+template <bool MOMENTUM>
+__device__ __forceinline__ void straggler_p2g_team(const TiledWork &w, const FixedGrid &g, const Params &P, int block, int blocks);
+
 // While a re-bin rides on the step, the momentum pass (bound by LDS and VALU, with memory bandwidth to
 // spare) also carries the columns no stage writes -- mass, colour, id -- to the particle's new slot.
+//
+// LISTED: the mass pass of this step ran on the same particles in the same slots and left the list of those
+// whose stencil is outside their arena (TiledState::listed).  This pass then lists nothing, and its follow-up
+// work -- those particles, straight to the global grid -- is done by the last workgroups of the same launch
+// (TiledWork::follow_from) instead of a launch of its own.
+template <bool LISTED>
 __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_P2G_WAVES)
 p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
+    if (LISTED && (int)blockIdx.x >= w.follow_from) {      // uniform
+        straggler_p2g_team<true>(w, g, P, (int)blockIdx.x - w.follow_from, (int)gridDim.x - w.follow_from);
+        return;
+    }
     const CtlHead head = load_head(w.ctl);
     const Store st{head.cur ? w.store.base[1] : w.store.base[0], w.store.capacity};
     int4 item;
@@ -1097,7 +1113,7 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         if (stencil_in_arena(s, A, &abase))
             p2g_momentum_particle<true>(s, in[kVelX], in[kVelY], in[kVelZ], in + kC00, dens + j,
                                         dens_out + d, lds, mass_f, abase, g, P);
-        else
+        else if (!LISTED)
             add_straggler(sg, sb, j);
         if (jn < item.z) {
 #pragma unroll
@@ -1106,7 +1122,7 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         j = jn;
     }
     stamp.end(0);
-    straggler_buf_flush(sg, sb);
+    if (!LISTED) straggler_buf_flush(sg, sb);
     __syncthreads();
     flush_arena<3>(lds, A, P, g);
 #if FLOWMPM_STAMPS
@@ -1323,20 +1339,20 @@ __device__ __forceinline__ float pick3(const float a[3], int i) { return i == 0 
 // side by side instead of one after the other, and the three cells of a z run fall into adjacent
 // records.  The density is the one quantity that couples the cells: it is summed in the reference's
 // order (SIM:353-364), every lane adding the 27 products one after the other.
+// block, blocks: this workgroup's index among the workgroups that share the work, and their number.
 template <bool MOMENTUM>
-__global__ void __launch_bounds__(256)
-straggler_p2g_team_kernel(TiledWork w, FixedGrid g, Params P)
+__device__ __forceinline__ void straggler_p2g_team(const TiledWork &w, const FixedGrid &g, const Params &P, int block, int blocks)
 {
     const Store st = w.store.pick();
     int count, tail_begin;
     const int total = straggler_total(w, &count, &tail_begin);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *w.sg.next_count = 0;
+    if (block == 0 && threadIdx.x == 0) *w.sg.next_count = 0;
     const int c = threadIdx.x & 31;                    // stencil cell of this lane (27..31: none)
     const int team_lane0 = threadIdx.x & 32;           // first lane of this team within the wave
     const int gx = c / 9, gy = (c / 3) % 3, gz = c % 3;
-    const int teams = gridDim.x * (blockDim.x >> 5);
+    const int teams = blocks * (blockDim.x >> 5);
     // every lane of a wave runs the same number of rounds (the shuffles below need the whole team)
-    for (int i0 = blockIdx.x * (blockDim.x >> 5) + ((threadIdx.x >> 6) << 1); i0 < total; i0 += teams) {
+    for (int i0 = block * (blockDim.x >> 5) + ((threadIdx.x >> 6) << 1); i0 < total; i0 += teams) {
         const int i = i0 + ((threadIdx.x >> 5) & 1);
         const bool live = i < total;
         const int j = !live ? 0 : (i < count ? w.sg.list[i] : tail_begin + (i - count));
@@ -1401,6 +1417,13 @@ straggler_p2g_team_kernel(TiledWork w, FixedGrid g, Params P)
             atomicAdd(g.cell + 4 * cell + 2, ez);
         }
     }
+}
+
+template <bool MOMENTUM>
+__global__ void __launch_bounds__(256)
+straggler_p2g_team_kernel(TiledWork w, FixedGrid g, Params P)
+{
+    straggler_p2g_team<MOMENTUM>(w, g, P, blockIdx.x, gridDim.x);
     if (!MOMENTUM && w.scan_here) {                      // uniform over the launch
         // every particle of the step has been counted once the last workgroup arrives here
         if (last_workgroup(&w.ctl->ticket) && w.ctl->riding == 2) {
@@ -1758,7 +1781,7 @@ inline TiledWork tiled_work(TiledState &T, StoreSel ss, long long n, StagePart s
                         T.straggler_list};
     if (sp.part != 1) T.stage_parity ^= 1;
     return TiledWork{ss, T.items, T.n_items, T.item_cap, T.key, T.rank, T.tile_count, T.tile_start, T.n_tiles, T.ctl, (int)n,
-                     tile_dims(T), sg, -2147483647 - 1, 2147483647, sp.part, sp.bnd_lo, sp.bnd_hi, 0, 0, 0, 0, 0, 0};
+                     tile_dims(T), sg, -2147483647 - 1, 2147483647, sp.part, sp.bnd_lo, sp.bnd_hi, 0, 0, 0, 0, 0, 0, 0};
 }
 
 // Upper bound of the work items any binning of n particles can produce.
@@ -1821,7 +1844,11 @@ inline int launch_p2g_mass_tiled(TiledState &T, StoreSel st, long long n, FixedG
                                  hipEvent_t ev_start, hipEvent_t ev_stop, int keep_lo = -2147483647 - 1,
                                  int keep_hi = 2147483647, bool defer_scan = false)
 {
-    T.listed = -1;      // this stage overwrites the one straggler list: a momentum pass's list is gone
+    // This stage overwrites the one straggler list.  Its own list serves the momentum pass and g2p of the step
+    // as long as the particles stay where they are -- not when it skips a slab's leavers, whose slots other
+    // particles take before the momentum pass runs.
+    const bool everything = keep_lo == -2147483647 - 1 && keep_hi == 2147483647;
+    T.listed = everything ? T.stage_parity : -1;
     TiledWork w = tiled_work(T, st, n);
     w.keep_lo = keep_lo;
     w.keep_hi = keep_hi;
@@ -1872,9 +1899,20 @@ inline int launch_p2g_momentum_tiled(TiledState &T, StoreSel st, long long n, Fi
                                      hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
                                      StagePart sp = kWholeStage)
 {
+    if (T.listed >= 0 && sp.part == 0) {
+        // the mass pass's list: one launch, the follow-up work in its last workgroups; the stage counts into
+        // no counter of its own (as in launch_g2p_tiled)
+        TiledWork w = tiled_work(T, st, n, StagePart{1, 0, 0});      // part 1: no change of counter
+        w.part = 0;
+        w.sg = Stragglers{T.straggler_counts + T.listed, T.straggler_counts + (T.listed ^ 1), T.straggler_list};
+        w.follow_from = (int)item_bound(T, n);
+        hipExtLaunchKernelGGL(p2g_momentum_tiled_kernel<true>, dim3(w.follow_from + straggler_blocks(n)), dim3(kTiledThreads),
+                              0, stream, ev_start, ev_stop, 0, w, g, P);
+        return 0;
+    }
     if (sp.part != 1) T.listed = T.stage_parity;      // with part 2 the list is complete
     const TiledWork w = tiled_work(T, st, n, sp);
-    hipExtLaunchKernelGGL(p2g_momentum_tiled_kernel, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream,
+    hipExtLaunchKernelGGL(p2g_momentum_tiled_kernel<false>, dim3(item_bound(T, n)), dim3(kTiledThreads), 0, stream,
                           ev_start, ev_stop, 0, w, g, P);
     if (sp.part != 1)
         hipLaunchKernelGGL(straggler_p2g_team_kernel<true>, dim3(straggler_blocks(n)), dim3(256), 0, stream, w, g, P);
