@@ -483,6 +483,25 @@ def test_rccl_world_of_one_sends_to_itself():
     rccl_selftest(0, 1 << 18)
 
 
+@pytest.mark.gpu
+def test_torch_distributed_path_over_rccl_in_a_world_of_one():
+    """Every torch.distributed call the slab simulation makes (init with a device id, the collectives, the
+    asynchronous count exchange on a side stream, batch_isend_irecv of halo words and records on device
+    buffers -- here to itself), with the "nccl" backend on the one GPU, and four steps of a one-slab
+    SlabSimulation over that group.  Says nothing about xGMI; catches what the gloo rehearsals cannot."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_selfcheck.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.strip().endswith("ok")
+    for line in ("all_gather_async_side_stream", "p2p_self_int32", "p2p_self_overlapped", "slab_world1_particles"):
+        assert "%-28s True" % line in r.stdout, r.stdout
+
+
 def test_limited_plane_starts_rule():
     from flow_amd.slab import limited_plane_starts, plane_starts_from_histogram
     hist = np.zeros(64, dtype=np.int64)
