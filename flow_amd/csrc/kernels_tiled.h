@@ -232,9 +232,11 @@ struct TiledWork {
     // item set of a riding re-bin (scan_tiles with these two) -- a grid of few tiles needs no launch of its own
     // for that.
     int scan_here, chunk, sparse;
-    // Momentum pass with the mass pass's list at hand (p2g_momentum_tiled_kernel<true>): the workgroups from
-    // this block index on are the pass's follow-up work (straggler_p2g_team) inside the same launch.
-    int follow_from;
+    // Momentum pass with the mass pass's list at hand (p2g_momentum_tiled_kernel<true>): the first
+    // follow_blocks workgroups of the launch are the pass's follow-up work (straggler_p2g_team), the work items
+    // start after them.  At the front they run next to the large items; at the back they were a tail of their
+    // own after the last small item.  Zero in every other launch.
+    int follow_blocks;
 };
 
 __device__ __forceinline__ int tile_of(float px, float py, float pz, const Params &P, TileDims td)
@@ -625,9 +627,9 @@ __device__ __forceinline__ void flush_arena(const int *lds, const Arena &A, cons
 // round-robin over the 8 XCDs, each with its own L2; handing every XCD one contiguous run of items
 // (neighbouring tiles share arena cells) measured 3 % slower on the ellipsoid scene, because such runs
 // hold unequal work, so block b simply takes item b.
-__device__ __forceinline__ int item_for_block(int n_items)
+__device__ __forceinline__ int item_for_block(int n_items, int first_block)
 {
-    const int b = blockIdx.x;
+    const int b = (int)blockIdx.x - first_block;
     if (b >= n_items) return -1;
     return b;
 }
@@ -640,7 +642,7 @@ __device__ __forceinline__ bool take_item(const TiledWork &w, const CtlHead &h, 
 {
     const int set = h.item_set;
     // (selects, not h.n_items[set]: a dynamically indexed copy of the head would live in scratch memory)
-    const int id = item_for_block(set ? h.n_items[1] : h.n_items[0]);
+    const int id = item_for_block(set ? h.n_items[1] : h.n_items[0], w.follow_blocks);
     if (id < 0) return false;
     const int large = set ? h.n_items[3] : h.n_items[2];      // these from the front of the list, the small ones from its back
     *item = w.items[(long long)set * w.item_cap + (id < large ? id : w.item_cap - 1 - (id - large))];
@@ -1062,14 +1064,14 @@ __device__ __forceinline__ void straggler_p2g_team(const TiledWork &w, const Fix
 //
 // LISTED: the mass pass of this step ran on the same particles in the same slots and left the list of those
 // whose stencil is outside their arena (TiledState::listed).  This pass then lists nothing, and its follow-up
-// work -- those particles, straight to the global grid -- is done by the last workgroups of the same launch
-// (TiledWork::follow_from) instead of a launch of its own.
+// work -- those particles, straight to the global grid -- is done by the first workgroups of the same launch
+// (TiledWork::follow_blocks) instead of a launch of its own.
 template <bool LISTED>
 __global__ void __launch_bounds__(kTiledThreads, FLOWMPM_P2G_WAVES)
 p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
 {
-    if (LISTED && (int)blockIdx.x >= w.follow_from) {      // uniform
-        straggler_p2g_team<true>(w, g, P, (int)blockIdx.x - w.follow_from, (int)gridDim.x - w.follow_from);
+    if (LISTED && (int)blockIdx.x < w.follow_blocks) {      // uniform
+        straggler_p2g_team<true>(w, g, P, (int)blockIdx.x, w.follow_blocks);
         return;
     }
     const CtlHead head = load_head(w.ctl);
@@ -1905,8 +1907,8 @@ inline int launch_p2g_momentum_tiled(TiledState &T, StoreSel st, long long n, Fi
         TiledWork w = tiled_work(T, st, n, StagePart{1, 0, 0});      // part 1: no change of counter
         w.part = 0;
         w.sg = Stragglers{T.straggler_counts + T.listed, T.straggler_counts + (T.listed ^ 1), T.straggler_list};
-        w.follow_from = (int)item_bound(T, n);
-        hipExtLaunchKernelGGL(p2g_momentum_tiled_kernel<true>, dim3(w.follow_from + straggler_blocks(n)), dim3(kTiledThreads),
+        w.follow_blocks = (int)straggler_blocks(n);
+        hipExtLaunchKernelGGL(p2g_momentum_tiled_kernel<true>, dim3(item_bound(T, n) + w.follow_blocks), dim3(kTiledThreads),
                               0, stream, ev_start, ev_stop, 0, w, g, P);
         return 0;
     }
