@@ -634,6 +634,20 @@ __device__ __forceinline__ int item_for_block(int n_items, int first_block)
     return b;
 }
 
+// Which slot of a trip's kTiledThreads consecutive slots a thread of the two scattering passes takes: lane l of
+// wave w takes slot l * (waves per workgroup) + w, so a wave holds every fourth slot instead of 64 consecutive
+// ones.  Particles that sit next to each other in the store tend to sit in the same cell once the fluid has
+// moved for a while (a re-bin keeps the order of those that stay and appends those that arrive together; at
+// 2^24 particles / 256^3, 220 steps in, two neighbouring slots share a cell with probability 0.10, slots four
+// apart with 0.03, random ones with 0.002 -- tools/slot_coherence.py), and lanes of a wave that share a cell
+// add to the same 27 or 81 LDS words one after the other.  The workgroup's waves still read and write the same
+// cache lines at the same time, a quarter of each.
+__device__ __forceinline__ int interleaved_thread()
+{
+    constexpr int kWaves = kTiledThreads / 64;
+    return (int)(threadIdx.x & 63u) * kWaves + (int)(threadIdx.x >> 6);
+}
+
 // The head of the control words, by one scalar load.
 __device__ __forceinline__ CtlHead load_head(const RebinCtl *ctl) { return *reinterpret_cast<const CtlHead *>(ctl); }
 
@@ -926,7 +940,7 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     // ones before it issues its atomics: a work item of this pass is a chain of memory round trips (the
     // compute units hold all the workgroups they can, eight each), and each of them taken off the chain
     // shortens the pass.
-    int j = item.y + threadIdx.x;
+    int j = item.y + interleaved_thread();
     float px = 0.0f, py = 0.0f, pz = 0.0f;
     if (j < item.z) { px = st.slot(kPosX)[j]; py = st.slot(kPosY)[j]; pz = st.slot(kPosZ)[j]; }
     for (int i = threadIdx.x; i < kArenaCells; i += kTiledThreads) lds[i] = 0;
@@ -1098,7 +1112,9 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     const Ride ride = ride_of(w, head, st);
     const Column<float> dens_out = ride.dst.slot(kDensity);
     float in[15];
-    int j = item.y + threadIdx.x;
+    // (while a re-bin rides on the step: the mapping under which the mass pass ranked the particles, so that
+    // a wave's lanes store to consecutive slots of the new binning)
+    int j = item.y + (head.riding != 0 ? interleaved_thread() : (int)threadIdx.x);
     if (j < item.z) {
 #pragma unroll
         for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
@@ -1222,7 +1238,7 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
     // Software pipeline: the next particle's loads are issued before this particle's 18 stores
     // (the memory counter retires in order, so a load issued after them would wait for them).
     G2PIn in;
-    int j = item.y + threadIdx.x;
+    int j = item.y + (head.riding != 0 ? interleaved_thread() : (int)threadIdx.x);      // as in the momentum pass
     auto load = [&](G2PIn &r, int q) {
         r.px = st.slot(kPosX)[q]; r.py = st.slot(kPosY)[q]; r.pz = st.slot(kPosZ)[q];
         // the mass is read by the mouse force alone (SIM:1354-1360)

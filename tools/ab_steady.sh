@@ -7,6 +7,7 @@ for v in "$@"; do
     python - <<PY
 import json
 d = json.load(open("gpurun_out/ab_$v.json")); s = d["steady"]
-print("%-8s %-24s first %6.2f steady %6.2f G/s | rebins %3d / %3d | stragglers/step %8.0f" % ("$v", "$args", d["value"] / 1e9, s["value"] / 1e9, d["rebin"]["performed"], s["rebins"], s["stragglers_per_step"]))
+short = lambda k: " ".join("%s %.4f" % (n, k[n]) for n in ("p2g1", "p2g2", "updateGrid", "g2p") if n in k)
+print("%-8s %-24s first %6.2f steady %6.2f G/s | rebins %3d / %3d | stragglers/step %6.0f | first: %s | steady: %s" % ("$v", "$args", d["value"] / 1e9, s["value"] / 1e9, d["rebin"]["performed"], s["rebins"], s["stragglers_per_step"], short({k: x["avg_ms"] for k, x in d["kernels"].items()}), short(s["kernel_avg_ms"])))
 PY
 done
