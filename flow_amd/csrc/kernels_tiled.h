@@ -998,9 +998,23 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
         nb_base[nb] = atomicAdd(&w.tile_count[tile], nb_count[nb]);
     }
     __syncthreads();
+    // Inside the block this workgroup reserved in a tile, whole runs of 64 ranks -- what one wave of this pass
+    // counted together, and what one wave of the momentum pass and of g2p will store together -- change places
+    // (run q goes where run q * p mod runs was, p coprime with the number of runs): the interleaving of the
+    // lanes alone only ever mixes the 256 slots of one trip among themselves, and four re-bins in a row put
+    // them back in their old order.
     for (int j = item.y + threadIdx.x; j < item.z; j += kTiledThreads) {
         const int r = w.rank[j];
-        if (r != kRankNotMine) w.rank[j] = nb_base[r >> kRankNbShift] + (r & ((1 << kRankNbShift) - 1));
+        if (r == kRankNotMine) continue;
+        const int nb = r >> kRankNbShift;
+        int local = r & ((1 << kRankNbShift) - 1);
+        const unsigned runs = (unsigned)nb_count[nb] >> 6;
+        const unsigned run = (unsigned)local >> 6;
+        if (run < runs && runs > 2u) {
+            const unsigned p = (runs % 257u) ? 257u : 263u;
+            local = (int)(((run * p) % runs) << 6) | (local & 63);
+        }
+        w.rank[j] = nb_base[nb] + local;
     }
 }
 
