@@ -65,7 +65,7 @@ struct EventPair {
 
 }  // namespace
 
-constexpr int kSlabRideDivisor = 512;      // measured on the 8 slabs of 2^27 particles / 512^3: 4096 -> 1.95, 2048 -> 1.96, 1024 -> 1.93, 512 -> 1.91 ms per slab step
+constexpr int kSlabRideDivisor = 256;      // measured on the 8 slabs of 2^27 particles / 512^3 (tools/divisor_sweep_slab.sh): 2048 -> 2.00, 1024 -> 1.98, 512 -> 1.96, 256 -> 1.91, 128 -> 1.91 ms per slab step
 
 struct flowmpm_sim {
     flowmpm_config cfg{};
@@ -790,9 +790,11 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
             // divisor 256 -> 10.17 / 7.78e9 per second, 512 -> 10.24 / 7.98, 1024 -> 10.22 / 7.98, 2048 -> 10.28 / 8.04).
             // With the count in the mass pass and the constant columns in the momentum pass (0.30 ms per re-bin):
             // 1024 -> 10.22 / 8.38, 4096 -> 10.31 / 8.21, 8192 -> 10.35 / 8.45, 16384 -> 10.37 / 8.48.
+            // With the store order mixed at every riding re-bin (a riding g2p then reads with a stride):
+            // 2048 -> 12.01 / 9.68, 4096 -> 12.04 / 9.67, 8192 -> 11.99 / 9.51, 16384 -> 12.00 / 9.62.
             // A slab takes in a few thousand arrivals per step, all outside the binning until the next re-bin and
             // each costing three stages of global atomics: with re-bins this cheap it re-bins every few steps.
-            if (s->ride_rebins) s->drift_divisor = s->slab ? kSlabRideDivisor : 8192;
+            if (s->ride_rebins) s->drift_divisor = s->slab ? kSlabRideDivisor : 4096;
             HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->dirty), (size_t)s->tiled.tiles_cap * sizeof(int)));
             HIP_TRY(s, hipMemsetAsync(s->dirty, 0, (size_t)s->tiled.tiles_cap * sizeof(int), s->stream));
         }

@@ -262,7 +262,7 @@ int flowmpm_set_mode_uniforms(flowmpm_sim *sim, const flowmpm_mode_uniforms *m);
  *   launch of its own, 0 the standalone two-launch re-bin (what flowmpm_run_kernel and slab handles
  *   always use).  The flowmpm_slab_step_* sequence of a slab handle rides in form 2 (or 0).
  * DRIFT_DIVISOR: the device re-bins when the particles outside their tile's arena, summed over the steps
- *   since the last re-bin, exceed particles / divisor (default 8192 riding, 512 riding on a slab, 256
+ *   since the last re-bin, exceed particles / divisor (default 4096 riding, 256 riding on a slab, 256
  *   standalone, 48 standalone on a slab;
  *   0 leaves only rebin_interval).
  * CHUNK: most particles per work item (256 .. 4096, default 4096).  SPARSE_TILE: tiles with fewer
