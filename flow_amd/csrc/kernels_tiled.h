@@ -50,6 +50,10 @@ constexpr int kArenaPad = kArenaCells + 8;     // component stride in LDS (dword
 constexpr int kTiledThreads = FLOWMPM_TILED_THREADS;
 constexpr int kChunkMax = 16 * kTiledThreads, kChunkMin = kTiledThreads;
 constexpr int kLargeItem = 1024;     // particles; see scan_tiles
+#ifndef FLOWMPM_MIX_EVERY
+#define FLOWMPM_MIX_EVERY 4
+#endif
+constexpr int kMixEvery = FLOWMPM_MIX_EVERY;      // riding re-bins per mixing one (p2g_mass_tiled_kernel)
 // Minimum waves per SIMD the register allocator must leave room for (second argument of
 // __launch_bounds__) in the two register-heavy kernels; measured, not guessed.
 #ifndef FLOWMPM_P2G_WAVES
@@ -132,7 +136,8 @@ struct alignas(32) RebinCtl {
     // into the particle's slot of the OTHER store, and the last workgroup of the step commits.
     int riding;      // latched by the step's binning launch: this step's stores go to the other store
                      // (1: that launch counted the tiles, 2: the step's mass pass counts them)
-    int head_pad;
+    int mixing;      // latched with `riding`: the ranks of this riding re-bin were handed out to every fourth
+                     // slot per wave (interleaved_thread), and the momentum pass and g2p read the same way
     int n_items[4];  // work items of the two sets, then the large ones among them (scan_tiles)
     // ---- end of the head ----
     int ticket;      // workgroups of the running binning kernel that have finished
@@ -159,7 +164,7 @@ struct alignas(32) RebinCtl {
 
 // The first 32 bytes of RebinCtl as one value.
 struct alignas(32) CtlHead {
-    int cur, item_set, riding, head_pad;
+    int cur, item_set, riding, mixing;
     int n_items[4];
 };
 static_assert(offsetof(RebinCtl, n_items) == offsetof(CtlHead, n_items) && offsetof(RebinCtl, riding) == offsetof(CtlHead, riding) &&
@@ -387,7 +392,7 @@ bin_count_scan_kernel(StoreSel ss, int n, Params P, TileDims td, int *__restrict
     // ride: the re-bin, if due, rides on this step (RebinCtl::riding) instead of being completed by
     // bin_scatter_kernel.  The decision is a pure function of words nothing changes before g2p.
     const bool due = rebin_due(ctl, n, interval, force, divisor);
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->riding = (ride && due) ? 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->riding = (ride && due) ? 1 : 0; ctl->mixing = 0; }
     if (!due) return;
     const int next_set = ctl->item_set ^ 1;
     tile_start += (long long)next_set * (n_tiles + 1);
@@ -927,7 +932,13 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     const Store st{head.cur ? w.store.base[1] : w.store.base[0], w.store.capacity};
     // counting for a riding re-bin (uniform over the launch)
     const bool counting = w.decide ? rebin_due(w.ctl, w.n, w.interval, 0, w.divisor) : head.riding == 2;
-    if (w.decide && blockIdx.x == 0 && threadIdx.x == 0) w.ctl->riding = counting ? 2 : 0;
+    // Every kMixEvery-th riding re-bin mixes the store order (see the end of this kernel): a mixing re-bin makes
+    // the momentum pass and g2p of its step read with a stride, which costs them 0.3 ms each at 2^24 particles.
+    const bool mixing = counting && (w.decide ? (w.ctl->rebins % kMixEvery) == 0 : head.mixing != 0);
+    if (w.decide && blockIdx.x == 0 && threadIdx.x == 0) {
+        w.ctl->riding = counting ? 2 : 0;
+        w.ctl->mixing = mixing ? 1 : 0;
+    }
     int4 item;
     if (!take_item(w, head, &item)) return;
     const Stragglers sg = w.sg;
@@ -940,7 +951,9 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     // ones before it issues its atomics: a work item of this pass is a chain of memory round trips (the
     // compute units hold all the workgroups they can, eight each), and each of them taken off the chain
     // shortens the pass.
-    int j = item.y + interleaved_thread();
+    // (a counting pass that does not mix keeps the slots in order: the ranks it hands out decide where the
+    // momentum pass and g2p of the step, which then read their particles in order, store them)
+    int j = item.y + (counting && !mixing ? (int)threadIdx.x : interleaved_thread());
     float px = 0.0f, py = 0.0f, pz = 0.0f;
     if (j < item.z) { px = st.slot(kPosX)[j]; py = st.slot(kPosY)[j]; pz = st.slot(kPosZ)[j]; }
     for (int i = threadIdx.x; i < kArenaCells; i += kTiledThreads) lds[i] = 0;
@@ -1128,7 +1141,7 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     float in[15];
     // (while a re-bin rides on the step: the mapping under which the mass pass ranked the particles, so that
     // a wave's lanes store to consecutive slots of the new binning)
-    int j = item.y + (head.riding != 0 ? interleaved_thread() : (int)threadIdx.x);
+    int j = item.y + (head.riding != 0 && head.mixing != 0 ? interleaved_thread() : (int)threadIdx.x);
     if (j < item.z) {
 #pragma unroll
         for (int k = 0; k < 15; k++) in[k] = st.slot(kPosX + k)[j];
@@ -1252,7 +1265,7 @@ g2p_tiled_kernel(TiledWork w, const float4 *__restrict__ cellf, Params P,
     // Software pipeline: the next particle's loads are issued before this particle's 18 stores
     // (the memory counter retires in order, so a load issued after them would wait for them).
     G2PIn in;
-    int j = item.y + (head.riding != 0 ? interleaved_thread() : (int)threadIdx.x);      // as in the momentum pass
+    int j = item.y + (head.riding != 0 && head.mixing != 0 ? interleaved_thread() : (int)threadIdx.x);      // as in the momentum pass
     auto load = [&](G2PIn &r, int q) {
         r.px = st.slot(kPosX)[q]; r.py = st.slot(kPosY)[q]; r.pz = st.slot(kPosZ)[q];
         // the mass is read by the mouse force alone (SIM:1354-1360)
