@@ -312,6 +312,18 @@ def run_single(args):
             window_values.append(n * args.steady_steps / (time.perf_counter() - t1))
             done += args.steady_steps
         after = h.timings()
+        # The per-kernel averages of the steady state come from one more window in which EVERY step is timed:
+        # a re-bin rides on every tenth step or so and costs its step's launches up to half as much again, so
+        # every 8-th step sampled can land on those steps far more or less often than their share (0.378 against
+        # 0.412 for the P2G fraction of one and the same run), and timing every step costs the windows above 0.8 %.
+        h.set_profiling(1)
+        before_kernels = h.timings()
+        t1 = time.perf_counter()
+        advance(done, args.steady_steps)
+        h.synchronize()
+        kernel_window_value = n * args.steady_steps / (time.perf_counter() - t1)
+        after_kernels = h.timings()
+        done += args.steady_steps
         steady_steps = args.steady_windows * args.steady_steps
         rebins = (after["rebin"].get("performed") or 0) - (before["rebin"].get("performed") or 0)
         rebin_ms = after["rebin"].get("performed_ms", 0.0) - before["rebin"].get("performed_ms", 0.0)
@@ -322,10 +334,14 @@ def run_single(args):
                   "rebin_ms_per_step": round(rebin_ms / steady_steps, 4),       # the scan launches only (see kernels.p2g_with_sort)
                   "stragglers_per_step": round(((after["rebin"].get("stragglers") or 0)
                                                 - (before["rebin"].get("stragglers") or 0)) / steady_steps, 1)}
-        steady_kernels = {name: {"ms": after[name]["ms"] - before[name]["ms"],
-                                 "launches": after[name]["launches"] - before[name]["launches"]} for name in BYTES}
+        steady_kernels = {name: {"ms": after_kernels[name]["ms"] - before_kernels[name]["ms"],
+                                 "launches": after_kernels[name]["launches"] - before_kernels[name]["launches"]} for name in BYTES}
         steady["kernel_avg_ms"] = {name: round(t["ms"] / t["launches"], 4)
                                    for name, t in steady_kernels.items() if t["launches"]}
+        # (the flow goes on: the window the averages come from is a later one, with its own throughput)
+        steady["kernel_window"] = {"steps": args.steady_steps, "first_step": done - args.steady_steps,
+                                   "value": round(kernel_window_value, 1),
+                                   "rebins": (after_kernels["rebin"].get("performed") or 0) - (before_kernels["rebin"].get("performed") or 0)}
     h.close()
     first_roof, per_kernel = roofline_of(timings, n, cells)
     # The line's roofline is the steady one whenever the steady windows ran: the timed window follows a
@@ -336,7 +352,7 @@ def run_single(args):
     # (clearGrid has no launch of its own in flowmpm_step: updateGrid zeroes the older fixed-point set)
     if steady is not None and all(steady_kernels[k]["launches"] for k in ("p2g1", "p2g2", "g2p")):
         roof, steady_per_kernel = roofline_of(steady_kernels, n, cells)
-        roof["window"] = "steady: %d steps after the timed window, every %d-th step sampled" % (steady_steps, args.timing_stride)
+        roof["window"] = "steady: the %d steps that follow the timed window and the %d steps of the steady throughput windows, every step timed" % (args.steady_steps, steady_steps)
         roof["first_window"] = {k: first_roof[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}
         steady["kernels"] = steady_per_kernel
     else:
