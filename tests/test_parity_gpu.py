@@ -362,6 +362,29 @@ def test_noise_with_a_negative_clock(oracle_binding, algo):
         h.close()
 
 
+def test_six_hundred_steps_of_riding_and_mixing_rebins_leave_the_bits_alone():
+    """2^20 particles on 128^3 with the reference's default noise, 600 steps: the device re-bins about every
+    fifth step, every re-bin rides on its step's launches, and every fourth one also changes the order of
+    the particles inside the tiles (interleaved lanes in the mass pass, runs of ranks changing places, the
+    momentum pass and g2p reading with a stride on that step).  None of that may show in the results: the
+    reference's own algorithm (one thread per particle, global atomics, no binning at all) must give the same
+    particles and the same fixed-point grid, bit for bit."""
+    grid, n = (128, 128, 128), 1 << 20
+    uni = dict(DEFAULT_UNIFORMS, noise=1.0, rest_density=n / (0.268 * 128 ** 3))
+    outs = []
+    for algo in (_lib.ALGO_TILED, _lib.ALGO_SCATTER):
+        h = flow_amd.Handle(grid, n, algorithm=algo, rebin_interval=64)
+        h.generate_particles(_lib.SCENE_ELLIPSOID, n, seed=77)
+        h.set_uniforms(**uni)
+        for _ in range(6):
+            h.step(100, 1.0 / 60)
+        outs.append((h.download_grid_i32(), h.download_particles(), h.timings()["rebin"].get("performed") or 0))
+        h.close()
+    assert outs[0][2] >= 40, "the run is meant to hold many re-bins, ten or more of them mixing: %d" % outs[0][2]
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert_bits_equal(outs[0][1], outs[1][1], "particles tiled vs scatter after 600 steps")
+
+
 def test_scatter_and_tiled_agree_at_full_size():
     """Benchmark configuration 2 (2^20 particles, 128^3): too big for the oracle in a test, so
     check what is size-independent: both algorithms produce identical bits, and the fixed-point
