@@ -790,7 +790,7 @@ int flowmpm_create(const flowmpm_config *config, flowmpm_sim **out)
             // divisor 256 -> 10.17 / 7.78e9 per second, 512 -> 10.24 / 7.98, 1024 -> 10.22 / 7.98, 2048 -> 10.28 / 8.04).
             // With the count in the mass pass and the constant columns in the momentum pass (0.30 ms per re-bin):
             // 1024 -> 10.22 / 8.38, 4096 -> 10.31 / 8.21, 8192 -> 10.35 / 8.45, 16384 -> 10.37 / 8.48.
-            // With the store order mixed at every riding re-bin (a riding g2p then reads with a stride):
+            // With the store order mixed by riding re-bins (the momentum pass and g2p of such a step read with a stride):
             // 2048 -> 12.01 / 9.68, 4096 -> 12.04 / 9.67, 8192 -> 11.99 / 9.51, 16384 -> 12.00 / 9.62.
             // A slab takes in a few thousand arrivals per step, all outside the binning until the next re-bin and
             // each costing three stages of global atomics: with re-bins this cheap it re-bins every few steps.

@@ -639,9 +639,11 @@ __device__ __forceinline__ int item_for_block(int n_items, int first_block)
     return b;
 }
 
-// Which slot of a trip's kTiledThreads consecutive slots a thread of the two scattering passes takes: lane l of
-// wave w takes slot l * (waves per workgroup) + w, so a wave holds every fourth slot instead of 64 consecutive
-// ones.  Particles that sit next to each other in the store tend to sit in the same cell once the fluid has
+// Which slot of a trip's kTiledThreads consecutive slots a thread takes when a wave is to hold every fourth slot
+// instead of 64 consecutive ones: lane l of wave w takes slot l * (waves per workgroup) + w.  The mass pass reads
+// this way (except when it counts for a re-bin that keeps the order); the momentum pass and g2p only on the step
+// of a re-bin whose ranks were handed out this way (RebinCtl::mixing), so that their stores are contiguous.
+// Particles that sit next to each other in the store tend to sit in the same cell once the fluid has
 // moved for a while (a re-bin keeps the order of those that stay and appends those that arrive together; at
 // 2^24 particles / 256^3, 220 steps in, two neighbouring slots share a cell with probability 0.10, slots four
 // apart with 0.03, random ones with 0.002 -- tools/slot_coherence.py), and lanes of a wave that share a cell
@@ -934,7 +936,7 @@ p2g_mass_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     const bool counting = w.decide ? rebin_due(w.ctl, w.n, w.interval, 0, w.divisor) : head.riding == 2;
     // Every kMixEvery-th riding re-bin mixes the store order (see the end of this kernel): a mixing re-bin makes
     // the momentum pass and g2p of its step read with a stride, which costs them 0.3 ms each at 2^24 particles.
-    const bool mixing = counting && (w.decide ? (w.ctl->rebins % kMixEvery) == 0 : head.mixing != 0);
+    const bool mixing = counting && (w.decide ? (w.ctl->epoch % kMixEvery) == 0 : head.mixing != 0);
     if (w.decide && blockIdx.x == 0 && threadIdx.x == 0) {
         w.ctl->riding = counting ? 2 : 0;
         w.ctl->mixing = mixing ? 1 : 0;
@@ -1139,8 +1141,8 @@ p2g_momentum_tiled_kernel(TiledWork w, FixedGrid g, Params P)
     const Ride ride = ride_of(w, head, st);
     const Column<float> dens_out = ride.dst.slot(kDensity);
     float in[15];
-    // (while a re-bin rides on the step: the mapping under which the mass pass ranked the particles, so that
-    // a wave's lanes store to consecutive slots of the new binning)
+    // (on the step of a mixing re-bin: the mapping under which the mass pass ranked the particles, so that a
+    // wave's lanes store to consecutive slots of the new binning)
     int j = item.y + (head.riding != 0 && head.mixing != 0 ? interleaved_thread() : (int)threadIdx.x);
     if (j < item.z) {
 #pragma unroll
@@ -1945,7 +1947,7 @@ inline int launch_p2g_momentum_tiled(TiledState &T, StoreSel st, long long n, Fi
                                      StagePart sp = kWholeStage)
 {
     if (T.listed >= 0 && sp.part == 0) {
-        // the mass pass's list: one launch, the follow-up work in its last workgroups; the stage counts into
+        // the mass pass's list: one launch, the follow-up work in its first workgroups; the stage counts into
         // no counter of its own (as in launch_g2p_tiled)
         TiledWork w = tiled_work(T, st, n, StagePart{1, 0, 0});      // part 1: no change of counter
         w.part = 0;
