@@ -59,6 +59,15 @@ int main()
     add("stride 2 words", v);
     for (int k = 0; k < 8; k++) for (int t = 0; t < 256; t++) v[k * 256 + t] = (t * 32 + k) % kWords;
     add("stride 32 words (same bank)", v);
+    // which lanes conflict: addresses with random rows and a prescribed residue
+    for (int k = 0; k < 8; k++) for (int t = 0; t < 256; t++) v[k * 256 + t] = (rand() % 120) * 32 + (t % 32);
+    add("distinct mod 32 per 32 lanes", v);
+    for (int k = 0; k < 8; k++) for (int t = 0; t < 256; t++) v[k * 256 + t] = (rand() % 60) * 64 + (t % 64);
+    add("distinct mod 64 per 64 lanes", v);
+    for (int k = 0; k < 8; k++) for (int t = 0; t < 256; t++) v[k * 256 + t] = (rand() % 120) * 32 + ((t % 16) * 2 + (t / 32) % 2);
+    add("distinct mod 32 per 16 lanes", v);
+    for (int k = 0; k < 8; k++) for (int t = 0; t < 256; t++) v[k * 256 + t] = (rand() % 30) * 128 + (t % 64) * 2;
+    add("distinct mod 128, even words", v);
     int *d_idx, *d_out;
     CHECK(hipMalloc(&d_idx, 8 * 256 * sizeof(int)));
     CHECK(hipMalloc(&d_out, 4));
