@@ -430,23 +430,26 @@ int stage_update_grid(flowmpm_sim *s, bool boundary_only = false, bool clear_old
     int rc = timing_events(s, FLOWMPM_KERNEL_UPDATE_GRID, &t, boundary_only);
     if (rc) return rc;
     unsigned blocks = std::min<long long>(blocks_for(s->local_cells, 256), 256 * 16);
-    // over the boundary tiles alone: the launch holds the always-visited tile columns only
     // (a workgroup per run of tiles along z)
-    int columns = s->tiled.tiles_x;
-    if (boundary_only) {
-        const mpm::TileRange r = s->tile_range();
-        columns = std::min(s->tiled.tiles_x, (r.always_lo + 1) + std::max(0, s->tiled.tiles_x - std::max(r.always_hi, r.always_lo + 1)));
-    }
     const int run = mpm::tile_run(s->tiled.n_tiles);
-    const unsigned tile_blocks = (unsigned)(columns * s->tiled.tiles_y * mpm::tile_runs_z(s->tiled.tiles_z, run));
+    const unsigned tile_blocks = (unsigned)(s->tiled.tiles_x * s->tiled.tiles_y * mpm::tile_runs_z(s->tiled.tiles_z, run));
     // the older set can be zeroed here when it is not the one being updated from
     const bool zero_old = clear_old && !boundary_only && s->dirty && s->mass_of_cellf != s->mass_i &&
                           s->mass_of_cellf == s->mass_spare;
-    if (s->dirty) {
+    if (boundary_only) {
+        // What the neighbours' momentum changed are the two pairs of planes the halo messages cover; every other
+        // cell of the boundary tile columns would be recomputed from unchanged words.
+        // (local planes 0, 1 and slab_nx, slab_nx + 1: halo_pair)
+        const long long plane = (long long)s->cfg.grid_y * s->cfg.grid_z;
+        const long long first_low = 0, first_high = (long long)s->cfg.slab_nx * plane, cells = 2 * plane;
+        hipExtLaunchKernelGGL(mpm::update_grid_ranges_kernel, dim3(std::min<long long>(blocks_for(2 * cells, 256), 256 * 16)),
+                              dim3(256), 0, s->stream, t.start, t.stop, 0, s->cell, s->mass_i, s->mass_of_cellf, s->cellf,
+                              first_low, first_high, cells, s->params);
+    } else if (s->dirty) {
         auto kernel = run == 1 ? mpm::update_grid_tiles_kernel<1> : mpm::update_grid_tiles_kernel<mpm::kTileRunMax>;
         hipExtLaunchKernelGGL(kernel, dim3(tile_blocks), dim3(256), 0, s->stream, t.start,
                               t.stop, 0, s->cell, s->mass_i, s->mass_of_cellf, s->cellf, s->dirty,
-                              boundary_only ? -1 : (s->mass_bit(s->mass_i) | s->mass_bit(s->mass_of_cellf)),
+                              s->mass_bit(s->mass_i) | s->mass_bit(s->mass_of_cellf),
                               mpm::tile_dims(s->tiled), s->params, s->tile_range(), s->cell_spare,
                               zero_old ? (s->cell_bit(s->cell_spare) | s->mass_bit(s->mass_spare)) : 0);
     } else

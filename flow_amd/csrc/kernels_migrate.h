@@ -270,7 +270,7 @@ inline int migration_reserve(MigrationScratch &M, long long want, std::string *m
 }
 
 // Workgroups of find_leavers_kernel: enough to fill the chip, few enough that the counters see few atomics.
-inline unsigned find_blocks(long long n) { return (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 1024)); }
+inline unsigned find_blocks(long long n) { return (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096)); }
 
 // Enqueues the classification of the n resident particles: leaver counts per destination
 // rank and the leaver list.  Nothing is read back here.  dev_counts (may be null) receives

@@ -244,6 +244,24 @@ update_grid_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass_i
     }
 }
 
+// The same over two runs of `cells` cells each, starting at first[0] and first[1] (a slab's two pairs of boundary
+// planes after the neighbours' momentum has been merged into them).
+__global__ void __launch_bounds__(256)
+update_grid_ranges_kernel(const int4 *__restrict__ cell, const int *__restrict__ mass_i,
+                          const int *__restrict__ mass_of_cellf, float4 *__restrict__ cellf, long long first0,
+                          long long first1, long long cells, Params P)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int plane = P.gy * P.gz;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < 2 * cells; k += stride) {
+        const long long i = k < cells ? first0 + k : first1 + (k - cells);
+        int lx = (int)(i / plane);
+        int rem = (int)(i - (long long)lx * plane);
+        int y = rem / P.gz;
+        update_grid_cell(cell, mass_i, mass_of_cellf, cellf, i, lx + P.x_off, y, rem - y * P.gz, P);
+    }
+}
+
 // SIM:431-1536, gathering straight from the global float grid.  MODES = false is the chaos
 // path (every mode uniform zero, M unused); MODES = true adds the mode branches.
 template <bool MODES>

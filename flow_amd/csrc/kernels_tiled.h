@@ -1642,16 +1642,11 @@ update_grid_tiles_kernel(const int4 *__restrict__ cell, const int *__restrict__ 
     static_assert(RUN == 1 || RUN == 2 || RUN == 4, "256 threads = 8 z x RUN tiles x 8 y x (4 / RUN) groups of planes");
     constexpr int kRunBits = RUN == 4 ? 2 : (RUN == 2 ? 1 : 0);
     constexpr int kPer = kTX * RUN / 4;             // planes (cells) per thread
-    // block -> (tile column tx, ty, run of z tiles).  bits < 0: the always-visited (boundary) tiles only, and
-    // the launch holds just their columns: tx runs over 0 .. always_lo, then the columns from always_hi on
+    // block -> (tile column tx, ty, run of z tiles)
     const int runs_z = (td.tiles_z + RUN - 1) / RUN;
     const int per_column = td.tiles_y * runs_z;
-    int tx = blockIdx.x / per_column;
+    const int tx = blockIdx.x / per_column;
     const int rest = blockIdx.x - tx * per_column;
-    if (bits < 0) {
-        const int hi_first = max(r.always_hi, r.always_lo + 1);      // (a thin slab: every column is a boundary column)
-        tx = tx <= r.always_lo ? tx : hi_first + (tx - r.always_lo - 1);
-    }
     const int ty = rest / runs_z, run = rest - ty * runs_z;
     const int zc = threadIdx.x & 7, q = (threadIdx.x >> 3) & (RUN - 1), row = (threadIdx.x >> (3 + kRunBits)) & 7,
               group = threadIdx.x >> (6 + kRunBits);
@@ -1661,7 +1656,7 @@ update_grid_tiles_kernel(const int4 *__restrict__ cell, const int *__restrict__ 
     const bool always = tx <= r.always_lo || tx >= r.always_hi;
     const int tile_bits = exists ? dirty[t] : 0;
     const bool zero_old = exists && clear_old_bits != 0 && (always || (tile_bits & clear_old_bits));
-    const bool visit = exists && (always || zero_old || (bits >= 0 && (tile_bits & bits)));
+    const bool visit = exists && (always || zero_old || (tile_bits & bits));
     const int y = ty * kTY + row, z = tz * kTZ + zc, lx0 = tx * kTX + group * kPer;
     if (visit && y < P.gy && z < P.gz && lx0 < P.local_nx) {
         const long long plane = (long long)P.gy * P.gz;
